@@ -1,0 +1,267 @@
+/*
+ * rt_abi.h — C ABI of libraytrace_hip.so, the MI355X-native replacement for the
+ * host→kernel call surface of SebLague/Ray-Tracing's compute path tracer.
+ *
+ * Every entry point below replaces a group of Unity ComputeShader / ComputeBuffer
+ * calls made by the reference dispatcher `Assets/Scripts/Tracer/RayComputeManager.cs`
+ * (RCM) on the kernels of `Assets/Scripts/Tracer/RayCompute.compute` (RCC) +
+ * `RayCommon.hlsl` (RC).  The cited file:line is the reference interface replaced.
+ *
+ * Conventions
+ *  - plain C, little-endian, 4-byte scalars, no padding inside the PODs (checked
+ *    by static asserts below and by the abi_size handshake in RtParams);
+ *  - matrices are Unity `Matrix4x4` memory order = column-major: m[c*4 + r];
+ *  - images are RGBA32F, W*H*16 bytes, row 0 = BOTTOM of the image (RC:555);
+ *  - every function returns RT_OK (0) or a negative RtStatus; text via rt_last_error;
+ *  - one context is externally synchronised (one caller thread at a time);
+ *  - the caller owns all host arrays (copied during the call).
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef enum RtStatus {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARG = -1,   /* null pointer, negative count, bad size        */
+    RT_ERR_ABI_MISMATCH = -2,  /* RtParams.abi_version / struct_size handshake   */
+    RT_ERR_NO_DEVICE = -3,     /* no HIP device / HIP runtime failure at create  */
+    RT_ERR_HIP = -4,           /* a HIP call failed (message in rt_last_error)   */
+    RT_ERR_STATE = -5,         /* call order wrong (render before resize/scene)  */
+    RT_ERR_SCENE = -6,         /* scene buffers inconsistent (index out of range,
+                                  BVH deeper than RT_MAX_BVH_DEPTH, ...)         */
+    RT_ERR_OOM = -7
+} RtStatus;
+
+/* Material flags — RayTracingMaterial.cs:7-12, RC:29-30 */
+enum { RT_MATERIAL_DEFAULT = 0, RT_MATERIAL_CHECKERED = 1, RT_MATERIAL_GLASS = 2 };
+
+/* BVH.cs:11-16 */
+enum { RT_BVH_QUALITY_LOW = 0, RT_BVH_QUALITY_HIGH = 1, RT_BVH_QUALITY_DISABLED = 2 };
+
+/* Deepest leaf the reference builder can emit (BVH.cs:91,101). The reference's
+ * traversal stack has 32 ints (RC:239) which a depth-32 leaf overflows; ours holds
+ * RT_MAX_BVH_DEPTH+2 entries so the result is defined for every tree the builder
+ * can produce.  rt_upload_scene rejects deeper trees with RT_ERR_SCENE. */
+#define RT_MAX_BVH_DEPTH 32
+
+/* RC:64-76 == RayTracingMaterial.cs:15-27 (88 bytes) */
+typedef struct RtMaterial {
+    float diffuseCol[4];
+    float emissionCol[4];
+    float specularCol[4];
+    float absorption[4];
+    float absorptionStrength; /* C# name: absorptionMultiplier */
+    float emissionStrength;
+    float smoothness;
+    float specularProbability;
+    float ior;
+    int32_t flag;
+} RtMaterial;
+
+/* RC:78-85 == RCM:256-263 nested MeshInfo (224 bytes) */
+typedef struct RtModel {
+    int32_t nodeOffset;
+    int32_t triOffset;
+    float worldToLocal[16]; /* column-major */
+    float localToWorld[16]; /* column-major */
+    RtMaterial material;
+} RtModel;
+
+/* RC:49-53 == BVH.cs:579-598 (72 bytes), mesh-local space */
+typedef struct RtTriangle {
+    float posA[3], posB[3], posC[3];
+    float normA[3], normB[3], normC[3];
+} RtTriangle;
+
+/* RC:87-95 == BVH.cs:432-457 (32 bytes). Leaf iff triangleCount > 0 (RC:246). */
+typedef struct RtBVHNode {
+    float boundsMin[3];
+    float boundsMax[3];
+    int32_t startIndex;
+    int32_t triangleCount;
+} RtBVHNode;
+
+/* Analytic sphere (104 bytes). NOT a buffer of the reference snapshot: the
+ * reference keeps the maths (RaySphere, RC:289-332) but its only call is
+ * commented out (RC:341).  BASELINE.json's configs use spheres, so the buffer is
+ * an additive extension hooked where the commented call sits: spheres are tested
+ * before the model loop, closest hit carried in result.dst, material taken from
+ * the sphere instead of the hard-coded debug material (RC:321-327). */
+typedef struct RtSphere {
+    float centre[3];
+    float radius;
+    RtMaterial material;
+} RtSphere;
+
+/* All per-dispatch uniforms of the kernel (RC:5-26,120-121; RCC:7-8), as set by
+ * RCM:139-140,156,165-180,188-189,203. */
+typedef struct RtParams {
+    uint32_t abi_version;  /* = RT_ABI_VERSION                                  */
+    uint32_t struct_size;  /* = sizeof(RtParams) — handshake                    */
+    int32_t maxBounceCount;   /* RCM:168 */
+    int32_t numRaysPerPixel;  /* RCM:169 */
+    int32_t frame;            /* RCM:165,178: first frame after a reset is 1    */
+    int32_t renderSeed;       /* RCM:179 */
+    int32_t useSky;           /* RCM:166 */
+    int32_t accumulate;       /* RCM:180 */
+    float defocusStrength;    /* RCM:170 */
+    float divergeStrength;    /* RCM:171 */
+    float sunFocus;           /* RCM:173 */
+    float sunIntensity;       /* RCM:174 */
+    float sunColour[3];       /* RCM:175 (rgb of the Color)                     */
+    float dirToSun[3];        /* RCM:176 */
+    float viewParams[3];      /* RCM:188 (planeWidth, planeHeight, focusDist)   */
+    float camLocalToWorld[16];/* RCM:189, column-major                          */
+} RtParams;
+
+/* Exact work counters of the frames rendered since the last rt_reset_counters.
+ * They are the `stats` idea of RC:254,271 made observable; algorithmic bytes
+ *  are computed from them.  `segments` is always exact; the
+ * other fields are only filled by frames rendered while stats are enabled
+ * (rt_enable_stats), otherwise they stay 0. */
+typedef struct RtCounters {
+    uint64_t segments;     /* CalculateRayCollision calls (RC:487)             */
+    uint64_t innerSteps;   /* popped inner nodes (2 box tests each, RC:262-282) */
+    uint64_t leafSteps;    /* popped leaf nodes (RC:248-261)                    */
+    uint64_t triTests;     /* RayTriangle calls (RC:253)                        */
+    uint64_t sphereTests;  /* RaySphere calls (extension)                       */
+    uint64_t modelVisits;  /* model-loop iterations (RC:347)                    */
+    uint64_t pixelFrames;  /* pixels written (W*H per frame)                    */
+    double gpuMs;          /* device time between rt_timer_begin / rt_timer_end  */
+} RtCounters;
+
+/* Build statistics of rt_build_bvh — BVH.cs:518-576 */
+typedef struct RtBvhStats {
+    int32_t triangleCount, totalNodeCount, leafNodeCount;
+    int32_t leafDepthMax, leafDepthMin, leafDepthSum;
+    int32_t leafMaxTriCount, leafMinTriCount;
+    int32_t quality;
+    double timeMs;
+} RtBvhStats;
+
+typedef struct RtContext RtContext;
+
+/* ---- lifetime: RCM:61-67 (OnEnable) / RCM:238-247 (OnDestroy -> Release) ---- */
+/* Creates a context rendering on HIP device `device_id` (one process per GPU).
+ * Fails with RT_ERR_NO_DEVICE if no MI355X-class HIP device is usable — there is
+ * no CPU fallback. */
+int rt_create(int device_id, RtContext** out);
+void rt_destroy(RtContext* ctx);
+const char* rt_last_error(const RtContext* ctx); /* ctx may be NULL: global msg */
+
+/* Run launches on an existing hipStream_t (e.g. torch's current stream); NULL =
+ * the context's own stream. */
+int rt_set_stream(RtContext* ctx, void* hip_stream);
+
+/* ---- render targets: RCM:126-141 InitTexturesAndBuffers -------------------- */
+/* Global image resolution (uniform `Resolution`, RCM:139); (re)allocates the
+ * library-owned FrameRender / AccumulatedRender for the rows this context owns
+ * and zeroes the accumulator (CH:305-313 recreates textures on size change). */
+int rt_resize(RtContext* ctx, int width, int height);
+
+/* Multi-GPU image tiling (no reference counterpart — the reference is single
+ * GPU): this context renders only strips s of `strip_rows` image rows with
+ * s % part_count == part_index (cyclic), using GLOBAL pixel ids / Resolution so
+ * every pixel is bit-identical to the single-GPU render.  The local buffers
+ * hold the owned rows, packed in increasing global row order.  Default (1
+ * part) = whole image.  strip_rows must be a multiple of 8.  Call before
+ * rt_resize or it re-allocates. */
+int rt_set_partition(RtContext* ctx, int strip_rows, int part_index, int part_count);
+/* Number of image rows this context owns (after rt_resize). */
+int rt_local_rows(const RtContext* ctx);
+/* Global row index of local row `local_row`. */
+int rt_local_to_global_row(const RtContext* ctx, int local_row);
+
+/* Optional: render into caller-owned DEVICE buffers (≙ cs.SetTexture, RCM:135-137),
+ * each local_rows*W*16 bytes, e.g. torch tensors to be gathered with RCCL.
+ * Passing NULL for either returns to the library-owned buffer. */
+int rt_bind_render_targets(RtContext* ctx, void* d_frame_render, void* d_accumulated);
+/* Device pointers of the current targets (library-owned or bound). */
+int rt_get_render_targets(RtContext* ctx, void** d_frame_render, void** d_accumulated);
+
+/* ---- scene: RCM:143-161 InitBVH (ComputeBuffer create + SetData) ----------- */
+/* models/triangles/nodes are exactly the reference's three structured buffers;
+ * spheres is the extension buffer (may be NULL/0).  Validates every index and
+ * the depth of every BVH reachable from a model. */
+int rt_upload_scene(RtContext* ctx,
+                    const RtModel* models, int n_models,
+                    const RtTriangle* triangles, int n_triangles,
+                    const RtBVHNode* nodes, int n_nodes,
+                    const RtSphere* spheres, int n_spheres);
+/* RCM:192-204 UpdateModels: refresh matrices + materials (offsets must not change). */
+int rt_update_models(RtContext* ctx, const RtModel* models, int n_models);
+/* Refresh sphere centres/radii/materials (extension; count must not change). */
+int rt_update_spheres(RtContext* ctx, const RtSphere* spheres, int n_spheres);
+
+/* ---- uniforms: RCM:163-190 SetShaderParams + UpdateCameraParams ------------ */
+int rt_set_params(RtContext* ctx, const RtParams* params);
+
+/* ---- dispatch ------------------------------------------------------------- */
+/* RCM:69-76 ResetAccumulatedRender → kernel ResetAccumulated (RCC:26-32); also
+ * sets the context's frame counter to 1. */
+int rt_reset_accumulation(RtContext* ctx);
+/* RCM:84-95 RenderFrame → kernel RayTrace (RCC:10-24). Renders one frame with
+ * uniform Frame = the context's frame counter (initialised from RtParams.frame
+ * by rt_set_params), then increments the counter if accumulate (RCM:94).
+ * Asynchronous: returns after enqueueing. */
+int rt_render_frame(RtContext* ctx);
+/* n consecutive frames Frame, Frame+1, ... (benchmark/batch helper; identical
+ * to n calls of rt_render_frame, accumulation order preserved). */
+int rt_render_frames(RtContext* ctx, int n);
+/* Wait for all enqueued work of this context. */
+int rt_synchronize(RtContext* ctx);
+/* Current frame counter (≙ numAccumulatedFrames, RCM:37). */
+int rt_get_frame(const RtContext* ctx);
+
+/* ---- readback (reference: none except ScreenCapture, RCM:106-111) --------- */
+/* Copy the locally owned rows (local_rows*W*16 bytes) to host memory;
+ * synchronises. `bytes` must be exactly that size. */
+int rt_read_frame(RtContext* ctx, float* rgba, size_t bytes);
+int rt_read_accumulated(RtContext* ctx, float* rgba, size_t bytes);
+
+/* ---- device timing ---------------------------------------------------------- */
+/* HIP events recorded on the stream the kernels are launched on: the device
+ * time between rt_timer_begin and rt_timer_end is added to RtCounters.gpuMs
+ * (read by rt_get_counters, which synchronises). */
+int rt_timer_begin(RtContext* ctx);
+int rt_timer_end(RtContext* ctx);
+
+/* ---- counters ------------------------------------------------------------- */
+int rt_enable_stats(RtContext* ctx, int enabled); /* detailed counters on/off */
+int rt_reset_counters(RtContext* ctx);
+int rt_get_counters(RtContext* ctx, RtCounters* out); /* synchronises */
+
+/* ---- host helpers so callers need not re-implement RCM/BVH host maths ------ */
+/* BVH.cs:26-318: builds the reference-shaped flat BVH of one mesh.
+ * verts/normals: n_verts*3 floats; indices: n_indices ints (3 per triangle).
+ * out_nodes must hold >= 2*max(1,n_indices/3) nodes, out_tris n_indices/3
+ * triangles. Pure host code (no device needed). */
+int rt_build_bvh(const float* verts, const float* normals, int n_verts,
+                 const int32_t* indices, int n_indices, int quality,
+                 RtBVHNode* out_nodes, int* out_n_nodes,
+                 RtTriangle* out_tris, RtBvhStats* out_stats);
+/* RCM:183-190 UpdateCameraParams: fills viewParams from (fovDeg, aspect, focusDist). */
+int rt_camera_view_params(float fov_deg, float aspect, float focus_distance, float out_view_params[3]);
+
+/* Library identification: returns "raytrace_hip gfx950 abi=<n>" */
+const char* rt_version(void);
+
+#ifdef __cplusplus
+} /* extern "C" */
+
+static_assert(sizeof(RtMaterial) == 88, "RtMaterial must be 88 bytes");
+static_assert(sizeof(RtModel) == 224, "RtModel must be 224 bytes");
+static_assert(sizeof(RtTriangle) == 72, "RtTriangle must be 72 bytes");
+static_assert(sizeof(RtBVHNode) == 32, "RtBVHNode must be 32 bytes");
+static_assert(sizeof(RtSphere) == 104, "RtSphere must be 104 bytes");
+#endif
+
+#endif /* RT_ABI_H */

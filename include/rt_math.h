@@ -1,0 +1,253 @@
+/*
+ * rt_math.h — the fp32 arithmetic contract of the path tracer.
+ *
+ * The reference shader (Assets/Scripts/Tracer/RayCommon.hlsl, "RC") runs under
+ * an HLSL compiler whose sqrt/div/log/cos/exp/pow are implementation-defined
+ * approximations, so "the reference's results" are only defined up to that.
+ * This header fixes one strict-IEEE binary32 definition of every non-trivial
+ * operation RC uses — written with +,-,*,/ , sqrt and integer ops only, no FMA
+ * contraction, no fast-math — so that the CPU oracle (g++ on x86-64) and the
+ * HIP kernels (hipcc on gfx950) evaluate the SAME rounding sequence and agree
+ * bit for bit.  A Monte-Carlo estimator with Russian roulette is chaotic in
+ * its random decisions; bit-exact primitives are what make a 1e-4 relative
+ * parity bar meaningful.
+ *
+ * Compile requirements (enforced by the build scripts):
+ *    host:   g++ -O2 -fno-fast-math -ffp-contract=off
+ *    device: hipcc -ffp-contract=off (f32 div/sqrt correctly rounded — the
+ *            hipcc default — and f32 denormals preserved — the gfx9 default).
+ *
+ * log/exp follow the classic Sun fdlibm single-precision algorithms, sin/cos
+ * the Cephes single-precision ones (Cody–Waite 3-term reduction + minimax
+ * polynomials); tests/test_math.py bounds their error against float64 libm.
+ */
+#ifndef RT_MATH_H
+#define RT_MATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+/* ---------------------------------------------------------------- bit casts */
+RT_HD uint32_t rt_f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+RT_HD float rt_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+
+#define RT_INF (rt_u2f(0x7f800000u))
+
+/* ------------------------------------------------- exact single operations */
+RT_HD float rt_sqrt(float x) { return __builtin_sqrtf(x); } /* correctly rounded */
+RT_HD float rt_abs(float x) { return rt_u2f(rt_f2u(x) & 0x7fffffffu); }
+RT_HD float rt_floor(float x) { return __builtin_floorf(x); } /* exact */
+
+/* HLSL min/max: if one operand is NaN the other is returned (RC:223-226 relies
+ * on this when invDir = inf meets a zero slab offset). */
+RT_HD float rt_min(float a, float b) { return (a < b || b != b) ? a : b; }
+RT_HD float rt_max(float a, float b) { return (a > b || b != b) ? a : b; }
+/* HLSL sign(): -1, 0 or +1 (0 for NaN) */
+RT_HD float rt_sign(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
+/* HLSL saturate(): clamp to [0,1], NaN -> 0 */
+RT_HD float rt_saturate(float x) { return rt_min(rt_max(x, 0.0f), 1.0f); }
+/* HLSL lerp(a,b,t) as compilers lower it: a + (b-a)*t */
+RT_HD float rt_lerp(float a, float b, float t) { return a + (b - a) * t; }
+/* HLSL smoothstep(a,b,x) */
+RT_HD float rt_smoothstep(float a, float b, float x)
+{
+    float t = rt_saturate((x - a) / (b - a));
+    return t * t * (3.0f - 2.0f * t);
+}
+
+/* ------------------------------------------------------------------- logf */
+RT_HD float rt_log(float x)
+{
+    const float ln2_hi = 6.9313812256e-01f; /* 0x3f317180 */
+    const float ln2_lo = 9.0580006145e-06f; /* 0x3717f7d1 */
+    const float Lg1 = 0.66666662693f, Lg2 = 0.40000972152f;
+    const float Lg3 = 0.28498786688f, Lg4 = 0.24279078841f;
+    uint32_t ix = rt_f2u(x);
+    int k = 0;
+    if (ix < 0x00800000u || (ix >> 31)) {
+        if ((ix << 1) == 0) return -RT_INF;          /* log(+-0) = -inf  */
+        if (ix >> 31) return rt_u2f(0x7fc00000u);     /* log(x<0) = NaN   */
+        k -= 25;                                       /* subnormal: scale */
+        x *= 33554432.0f;
+        ix = rt_f2u(x);
+    } else if (ix >= 0x7f800000u) {
+        return x;                                      /* inf or NaN       */
+    } else if (ix == 0x3f800000u) {
+        return 0.0f;
+    }
+    /* x = 2^k * (1+f), sqrt(2)/2 < 1+f < sqrt(2) */
+    ix += 0x3f800000u - 0x3f3504f3u;
+    k += (int)(ix >> 23) - 0x7f;
+    ix = (ix & 0x007fffffu) + 0x3f3504f3u;
+    x = rt_u2f(ix);
+    float f = x - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float w = z * z;
+    float t1 = w * (Lg2 + w * Lg4);
+    float t2 = z * (Lg1 + w * Lg3);
+    float R = t2 + t1;
+    float hfsq = 0.5f * f * f;
+    float dk = (float)k;
+    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+}
+
+/* ------------------------------------------------------------------- expf */
+RT_HD float rt_exp(float x)
+{
+    const float ln2hi = 6.9314575195e-1f;  /* 0x3f317200 */
+    const float ln2lo = 1.4286067653e-6f;  /* 0x35bfbe8e */
+    const float invln2 = 1.4426950216e+0f;
+    const float P1 = 1.6666625440e-1f, P2 = -2.7667332906e-3f;
+    uint32_t hx = rt_f2u(x);
+    int sign = (int)(hx >> 31);
+    hx &= 0x7fffffffu;
+    if (hx >= 0x42aeac50u) {               /* |x| >= 87.33655 or NaN */
+        if (hx > 0x7f800000u) return x;    /* NaN */
+        if (hx >= 0x42b17218u && !sign) return RT_INF;  /* overflow  */
+        if (sign && hx >= 0x42cff1b5u) return 0.0f;     /* underflow */
+    }
+    float hi, lo;
+    int k;
+    if (hx > 0x3eb17218u) {                /* |x| > 0.5 ln2 */
+        if (hx > 0x3f851592u)              /* |x| > 1.5 ln2 */
+            k = (int)(invln2 * x + (sign ? -0.5f : 0.5f));
+        else
+            k = 1 - sign - sign;
+        float fk = (float)k;
+        hi = x - fk * ln2hi;
+        lo = fk * ln2lo;
+        x = hi - lo;
+    } else if (hx > 0x39000000u) {         /* |x| > 2^-14 */
+        k = 0;
+        hi = x;
+        lo = 0.0f;
+    } else {
+        return 1.0f + x;
+    }
+    float xx = x * x;
+    float c = x - xx * (P1 + xx * P2);
+    float y = 1.0f + (x * c / (2.0f - c) - lo + hi);
+    if (k == 0) return y;
+    /* y * 2^k with a single rounding even when the result is subnormal */
+    if (k > 127) { y *= 1.7014118346e38f; k -= 127; }          /* 2^127 */
+    if (k < -126) {
+        y *= rt_u2f((uint32_t)(k + 24 + 127) << 23);
+        return y * 5.9604644775e-8f;                              /* 2^-24 */
+    }
+    return y * rt_u2f((uint32_t)(k + 127) << 23);
+}
+
+/* HLSL pow(x,y) for x >= 0, lowered the way GPUs do it (exp(y*log x)):
+ * pow(0,y>0) = 0, pow(1,y) = 1, pow(x<0,y) = NaN. */
+RT_HD float rt_pow(float x, float y) { return rt_exp(y * rt_log(x)); }
+
+/* -------------------------------------------------------------- sinf / cosf */
+/* r = x - n*(pi/2), n = round(x*2/pi); three-term Cody–Waite split of pi/2
+ * (8 + 11 + 24 significant bits: n*P1 and n*P2 are exact for |n| < 2^13).
+ * Accurate for |x| up to a few thousand; the tracer only passes [0, 2*pi]. */
+RT_HD int rt_reduce_pio2(float x, float* r)
+{
+    const float TWO_OVER_PI = 0.636619772f;
+    const float P1 = 1.5703125f;
+    const float P2 = 4.837512969970703125e-4f;
+    const float P3 = 7.54978995489188216e-8f;
+    float q = x * TWO_OVER_PI;
+    int n = (int)(q + (q < 0.0f ? -0.5f : 0.5f));
+    float fn = (float)n;
+    float t = x - fn * P1;
+    t = t - fn * P2;
+    t = t - fn * P3;
+    *r = t;
+    return n;
+}
+RT_HD float rt_sin_kernel(float r)
+{
+    float z = r * r;
+    float p = (-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f;
+    return r + r * z * p;
+}
+RT_HD float rt_cos_kernel(float r)
+{
+    float z = r * r;
+    float p = (2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f;
+    return 1.0f - 0.5f * z + z * z * p;
+}
+RT_HD float rt_sin(float x)
+{
+    if (!(rt_abs(x) < 3.0e4f)) return (x != x || rt_abs(x) == RT_INF) ? rt_u2f(0x7fc00000u) : 0.0f;
+    float r;
+    int n = rt_reduce_pio2(x, &r);
+    float s = (n & 1) ? rt_cos_kernel(r) : rt_sin_kernel(r);
+    return (n & 2) ? -s : s;
+}
+RT_HD float rt_cos(float x)
+{
+    if (!(rt_abs(x) < 3.0e4f)) return (x != x || rt_abs(x) == RT_INF) ? rt_u2f(0x7fc00000u) : 1.0f;
+    float r;
+    int n = rt_reduce_pio2(x, &r);
+    float c = (n & 1) ? rt_sin_kernel(r) : rt_cos_kernel(r);
+    return ((n + 1) & 2) ? -c : c;
+}
+
+/* ---------------------------------------------------------------- vectors */
+struct rt_f3 { float x, y, z; };
+struct rt_f2 { float x, y; };
+
+RT_HD rt_f3 rt_v3(float x, float y, float z) { rt_f3 r = {x, y, z}; return r; }
+RT_HD rt_f3 rt_v3s(float s) { rt_f3 r = {s, s, s}; return r; }
+RT_HD rt_f3 operator+(rt_f3 a, rt_f3 b) { return rt_v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD rt_f3 operator-(rt_f3 a, rt_f3 b) { return rt_v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD rt_f3 operator*(rt_f3 a, rt_f3 b) { return rt_v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_HD rt_f3 operator*(rt_f3 a, float s) { return rt_v3(a.x * s, a.y * s, a.z * s); }
+RT_HD rt_f3 operator*(float s, rt_f3 a) { return rt_v3(s * a.x, s * a.y, s * a.z); }
+RT_HD rt_f3 operator/(rt_f3 a, float s) { return rt_v3(a.x / s, a.y / s, a.z / s); }
+RT_HD rt_f3 operator-(rt_f3 a) { return rt_v3(-a.x, -a.y, -a.z); }
+/* HLSL dot(): left-to-right sum of products */
+RT_HD float rt_dot(rt_f3 a, rt_f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_HD rt_f3 rt_cross(rt_f3 a, rt_f3 b)
+{
+    return rt_v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+/* HLSL normalize(): defined here as v / sqrt(dot(v,v)) (correctly rounded sqrt
+ * and divide; a zero vector gives NaNs exactly like 0 * rsqrt(0)). */
+RT_HD rt_f3 rt_normalize(rt_f3 v) { return v / rt_sqrt(rt_dot(v, v)); }
+RT_HD rt_f3 rt_lerp3(rt_f3 a, rt_f3 b, float t)
+{
+    return rt_v3(rt_lerp(a.x, b.x, t), rt_lerp(a.y, b.y, t), rt_lerp(a.z, b.z, t));
+}
+/* HLSL intrinsic reflect(i,n) = i - 2*n*dot(i,n)  (RC:526); also RC:419-422 */
+RT_HD rt_f3 rt_reflect(rt_f3 i, rt_f3 n) { return i - (2.0f * rt_dot(i, n)) * n; }
+
+/* mul(M, float4(v, w)).xyz with M column-major (Unity Matrix4x4 memory order):
+ * row r = m[r]*v.x + m[4+r]*v.y + m[8+r]*v.z + m[12+r]*w, summed left to right */
+RT_HD rt_f3 rt_mul_point(const float* m, rt_f3 v, float w)
+{
+    return rt_v3(m[0] * v.x + m[4] * v.y + m[8] * v.z + m[12] * w,
+                 m[1] * v.x + m[5] * v.y + m[9] * v.z + m[13] * w,
+                 m[2] * v.x + m[6] * v.y + m[10] * v.z + m[14] * w);
+}
+
+/* ------------------------------------------------------------------- RNG */
+/* PCG hash step — RC:127-133 */
+RT_HD uint32_t rt_next_random(uint32_t* state)
+{
+    *state = *state * 747796405u + 2891336453u;
+    uint32_t result = ((*state >> ((*state >> 28) + 4u)) ^ *state) * 277803737u;
+    result = (result >> 22) ^ result;
+    return result;
+}
+/* RC:135-138: NextRandom / 4294967295.0 — the literal is a float, i.e. 2^32;
+ * uint->float conversion rounds to nearest even, the divide is exact.
+ * Range [0,1] INCLUSIVE (quirk Q4). */
+RT_HD float rt_random_value(uint32_t* state)
+{
+    return (float)rt_next_random(state) / 4294967296.0f;
+}
+
+#endif /* RT_MATH_H */

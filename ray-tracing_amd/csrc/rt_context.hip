@@ -1,0 +1,717 @@
+/*
+ * rt_context.hip — the C ABI of libraytrace_hip.so (include/rt_abi.h): context,
+ * scene validation + re-layout for HBM, render-target ownership, launches.
+ *
+ * Replaces the call surface RayComputeManager.cs ("RCM") drives on Unity's
+ * ComputeShader/ComputeBuffer objects; see rt_abi.h for the per-function map.
+ * There is no CPU fallback: without a HIP device rt_create fails.
+ */
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "rt_kernels.h"
+
+#define RT_VERSION_STRING "raytrace_hip gfx950 abi=1"
+
+static thread_local char g_err[512] = "";
+
+struct RtContext {
+    int device = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+
+    /* image */
+    int W = 0, H = 0;
+    int stripRows = 8, partIndex = 0, partCount = 1;
+    int localRows = 0;
+    float* ownFrame = nullptr;
+    float* ownAccum = nullptr;
+    size_t ownBytes = 0;
+    float* boundFrame = nullptr;
+    float* boundAccum = nullptr;
+
+    /* scene (device) */
+    float* dSpheres = nullptr;
+    DMaterial* dMaterials = nullptr;
+    DModel* dModels = nullptr;
+    DPair* dPairs = nullptr;
+    DTri* dTris = nullptr;
+    DTriN* dNorms = nullptr;
+    uint32_t* dBigLeaves = nullptr;
+    int nSpheres = 0, nModels = 0, nTris = 0, nPairs = 0;
+    bool haveScene = false;
+    /* scene (host mirrors needed by rt_update_models) */
+    std::vector<RtModel> hModels;
+    std::vector<uint32_t> hRootCodes;
+
+    /* uniforms */
+    RtParams params;
+    bool haveParams = false;
+    int frame = 1;
+
+    /* counters */
+    unsigned long long* dCounters = nullptr;
+    bool stats = false;
+    uint64_t pixelFrames = 0;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    double gpuMs = 0;
+    int timerState = 0; /* 0 idle, 1 begun, 2 ended (elapsed not yet read) */
+};
+
+static int fail(RtContext* ctx, int status, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", buf);
+    snprintf(g_err, sizeof(g_err), "%s", buf);
+    return status;
+}
+
+#define HIP_TRY(ctx, call)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+static int local_rows_for(int H, int stripRows, int partIndex, int partCount)
+{
+    int rows = 0;
+    int nStrips = (H + stripRows - 1) / stripRows;
+    for (int s = partIndex; s < nStrips; s += partCount) {
+        int r0 = s * stripRows;
+        int r1 = r0 + stripRows < H ? r0 + stripRows : H;
+        rows += r1 - r0;
+    }
+    return rows;
+}
+
+static void flush_timer(RtContext* ctx)
+{
+    if (ctx->timerState == 2) {
+        hipEventSynchronize(ctx->evStop);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop) == hipSuccess) ctx->gpuMs += ms;
+        ctx->timerState = 0;
+    }
+}
+
+extern "C" {
+
+const char* rt_version(void) { return RT_VERSION_STRING; }
+
+const char* rt_last_error(const RtContext* ctx) { return ctx ? ctx->err : g_err; }
+
+int rt_create(int device_id, RtContext** out)
+{
+    if (!out) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, RT_ERR_NO_DEVICE, "rt_create: no HIP device (%s); libraytrace_hip has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: device %d out of range [0,%d)", device_id, n);
+    RtContext* ctx = new RtContext();
+    ctx->device = device_id;
+    HIP_TRY(ctx, hipSetDevice(device_id));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking));
+    ctx->stream = ctx->ownStream;
+    HIP_TRY(ctx, hipMalloc(&ctx->dCounters, sizeof(unsigned long long) * RT_COUNTER_SLOTS * RT_COUNTER_FIELDS));
+    HIP_TRY(ctx, hipMemset(ctx->dCounters, 0, sizeof(unsigned long long) * RT_COUNTER_SLOTS * RT_COUNTER_FIELDS));
+    HIP_TRY(ctx, hipEventCreate(&ctx->evStart));
+    HIP_TRY(ctx, hipEventCreate(&ctx->evStop));
+    memset(&ctx->params, 0, sizeof(ctx->params));
+    *out = ctx;
+    return RT_OK;
+}
+
+static void free_scene(RtContext* ctx)
+{
+    hipFree(ctx->dSpheres); ctx->dSpheres = nullptr;
+    hipFree(ctx->dMaterials); ctx->dMaterials = nullptr;
+    hipFree(ctx->dModels); ctx->dModels = nullptr;
+    hipFree(ctx->dPairs); ctx->dPairs = nullptr;
+    hipFree(ctx->dTris); ctx->dTris = nullptr;
+    hipFree(ctx->dNorms); ctx->dNorms = nullptr;
+    hipFree(ctx->dBigLeaves); ctx->dBigLeaves = nullptr;
+    ctx->haveScene = false;
+}
+
+void rt_destroy(RtContext* ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    hipFree(ctx->ownFrame);
+    hipFree(ctx->ownAccum);
+    hipFree(ctx->dCounters);
+    if (ctx->evStart) hipEventDestroy(ctx->evStart);
+    if (ctx->evStop) hipEventDestroy(ctx->evStop);
+    if (ctx->ownStream) hipStreamDestroy(ctx->ownStream);
+    delete ctx;
+}
+
+int rt_set_stream(RtContext* ctx, void* hip_stream)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    hipStreamSynchronize(ctx->stream);
+    flush_timer(ctx);
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->ownStream;
+    return RT_OK;
+}
+
+int rt_set_partition(RtContext* ctx, int strip_rows, int part_index, int part_count)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (strip_rows <= 0 || strip_rows % 8 || part_count <= 0 || part_index < 0 || part_index >= part_count)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_set_partition: strip_rows must be a positive multiple of 8, 0 <= index < count");
+    ctx->stripRows = strip_rows;
+    ctx->partIndex = part_index;
+    ctx->partCount = part_count;
+    if (ctx->W > 0) return rt_resize(ctx, ctx->W, ctx->H);
+    return RT_OK;
+}
+
+int rt_resize(RtContext* ctx, int width, int height)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (width <= 0 || height <= 0) return fail(ctx, RT_ERR_INVALID_ARG, "rt_resize: %dx%d", width, height);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->W = width;
+    ctx->H = height;
+    ctx->localRows = local_rows_for(height, ctx->stripRows, ctx->partIndex, ctx->partCount);
+    size_t bytes = (size_t)ctx->localRows * width * 16;
+    if (bytes != ctx->ownBytes) {
+        hipFree(ctx->ownFrame); ctx->ownFrame = nullptr;
+        hipFree(ctx->ownAccum); ctx->ownAccum = nullptr;
+        ctx->ownBytes = 0;
+        if (bytes) {
+            HIP_TRY(ctx, hipMalloc(&ctx->ownFrame, bytes));
+            HIP_TRY(ctx, hipMalloc(&ctx->ownAccum, bytes));
+            ctx->ownBytes = bytes;
+        }
+    }
+    if (bytes) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->ownFrame, 0, bytes, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->ownAccum, 0, bytes, ctx->stream));
+    }
+    ctx->boundFrame = ctx->boundAccum = nullptr;
+    return RT_OK;
+}
+
+int rt_local_rows(const RtContext* ctx) { return ctx ? ctx->localRows : RT_ERR_INVALID_ARG; }
+
+int rt_local_to_global_row(const RtContext* ctx, int local_row)
+{
+    if (!ctx || local_row < 0 || local_row >= ctx->localRows) return RT_ERR_INVALID_ARG;
+    int ls = local_row / ctx->stripRows;
+    return (ls * ctx->partCount + ctx->partIndex) * ctx->stripRows + (local_row - ls * ctx->stripRows);
+}
+
+int rt_bind_render_targets(RtContext* ctx, void* d_frame, void* d_accum)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (((uintptr_t)d_frame | (uintptr_t)d_accum) & 15) return fail(ctx, RT_ERR_INVALID_ARG, "render targets must be 16-byte aligned");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->boundFrame = (float*)d_frame;
+    ctx->boundAccum = (float*)d_accum;
+    return RT_OK;
+}
+
+int rt_get_render_targets(RtContext* ctx, void** d_frame, void** d_accum)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (d_frame) *d_frame = ctx->boundFrame ? ctx->boundFrame : ctx->ownFrame;
+    if (d_accum) *d_accum = ctx->boundAccum ? ctx->boundAccum : ctx->ownAccum;
+    return RT_OK;
+}
+
+} /* extern "C" */
+
+/* ---------------------------------------------------------------- scene */
+static void pack_material(const RtMaterial& m, DMaterial& d)
+{
+    memset(&d, 0, sizeof(d));
+    memcpy(d.diffuseCol, m.diffuseCol, 16);
+    memcpy(d.emissionCol, m.emissionCol, 16);
+    memcpy(d.specularCol, m.specularCol, 16);
+    memcpy(d.absorption, m.absorption, 16);
+    d.absorptionStrength = m.absorptionStrength;
+    d.emissionStrength = m.emissionStrength;
+    d.smoothness = m.smoothness;
+    d.specularProbability = m.specularProbability;
+    d.ior = m.ior;
+    d.flag = m.flag;
+}
+static void pack_model(const RtModel& m, uint32_t rootCode, DModel& d)
+{
+    memset(&d, 0, sizeof(d));
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) {
+            d.w2l[r * 4 + c] = m.worldToLocal[c * 4 + r];
+            d.l2w[r * 4 + c] = m.localToWorld[c * 4 + r];
+        }
+    d.rootCode = rootCode;
+    d.triBase = m.triOffset;
+    d.cullBackface = m.material.flag != RT_MATERIAL_GLASS; /* RC:355 */
+}
+
+struct SceneBuilder {
+    const RtBVHNode* nodes;
+    int nNodes, nTris;
+    std::vector<DPair> pairs;
+    std::vector<uint32_t> bigLeaves;
+    std::vector<int32_t> pairOfFirstChild; /* absolute first-child node index -> pair id, -1 unseen, -2 in progress */
+    std::vector<int32_t> pairDepth;        /* height of the subtree below pair (levels) */
+    std::string error;
+
+    /* code of a leaf node whose triangles are [start, start+count) relative to triOffset */
+    bool leaf_code(const RtBVHNode& n, int triOffset, uint32_t* code)
+    {
+        long long lo = (long long)triOffset + n.startIndex, hi = lo + n.triangleCount;
+        if (n.startIndex < 0 || lo < 0 || hi > nTris) {
+            error = "leaf triangle range out of bounds";
+            return false;
+        }
+        if (n.triangleCount <= RT_CODE_MAX_INLINE_COUNT && (uint32_t)n.startIndex <= RT_CODE_MAX_INLINE_START) {
+            *code = RT_CODE_LEAF | ((uint32_t)n.triangleCount << 24) | (uint32_t)n.startIndex;
+        } else {
+            uint32_t idx = (uint32_t)(bigLeaves.size() / 2);
+            if (idx > RT_CODE_MAX_INLINE_START) { error = "too many oversized leaves"; return false; }
+            bigLeaves.push_back((uint32_t)n.startIndex);
+            bigLeaves.push_back((uint32_t)n.triangleCount);
+            *code = RT_CODE_LEAF | idx;
+        }
+        return true;
+    }
+
+    /* Converts the subtree under node `abs` (absolute index) of a mesh whose node 0 is at nodeOffset.
+     * Returns its code and height (leaf = 0). Iterative post-order walk, memoised per sibling pair. */
+    bool convert(int nodeOffset, int triOffset, int absRoot, uint32_t* codeOut, int* heightOut)
+    {
+        struct Frame { int abs; int stage; int firstChild; uint32_t codeA, codeB; int hA, hB; };
+        std::vector<Frame> stack;
+        stack.push_back({absRoot, 0, -1, 0, 0, 0, 0});
+        uint32_t retCode = 0;
+        int retHeight = 0;
+        while (!stack.empty()) {
+            Frame& f = stack.back();
+            const RtBVHNode& n = nodes[f.abs];
+            if (f.stage == 0) {
+                if (n.triangleCount > 0) { /* leaf — RC:246 */
+                    if (!leaf_code(n, triOffset, &retCode)) return false;
+                    retHeight = 0;
+                    stack.pop_back();
+                    continue;
+                }
+                long long fc = (long long)nodeOffset + n.startIndex;
+                if (n.startIndex < 0 || fc < 0 || fc + 1 >= nNodes) { error = "inner node child index out of bounds"; return false; }
+                f.firstChild = (int)fc;
+                int known = pairOfFirstChild[f.firstChild];
+                if (known == -2) { error = "cycle in BVH node graph"; return false; }
+                if (known >= 0) {
+                    retCode = (uint32_t)known;
+                    retHeight = pairDepth[known];
+                    stack.pop_back();
+                    continue;
+                }
+                if ((int)stack.size() > RT_MAX_BVH_DEPTH + 1) { error = "BVH deeper than RT_MAX_BVH_DEPTH"; return false; }
+                pairOfFirstChild[f.firstChild] = -2;
+                f.stage = 1;
+                int child = f.firstChild;
+                stack.push_back({child, 0, -1, 0, 0, 0, 0});
+                continue;
+            }
+            if (f.stage == 1) {
+                f.codeA = retCode;
+                f.hA = retHeight;
+                f.stage = 2;
+                int child = f.firstChild + 1;
+                stack.push_back({child, 0, -1, 0, 0, 0, 0});
+                continue;
+            }
+            /* stage 2: both children done */
+            f.codeB = retCode;
+            f.hB = retHeight;
+            const RtBVHNode& A = nodes[f.firstChild];
+            const RtBVHNode& B = nodes[f.firstChild + 1];
+            DPair p;
+            memset(&p, 0, sizeof(p));
+            memcpy(p.aMin, A.boundsMin, 12); memcpy(p.aMax, A.boundsMax, 12);
+            memcpy(p.bMin, B.boundsMin, 12); memcpy(p.bMax, B.boundsMax, 12);
+            p.codeA = f.codeA;
+            p.codeB = f.codeB;
+            int id = (int)pairs.size();
+            pairs.push_back(p);
+            int h = 1 + (f.hA > f.hB ? f.hA : f.hB);
+            pairDepth.push_back(h);
+            pairOfFirstChild[f.firstChild] = id;
+            retCode = (uint32_t)id;
+            retHeight = h;
+            stack.pop_back();
+        }
+        *codeOut = retCode;
+        *heightOut = retHeight;
+        return true;
+    }
+};
+
+template <typename T>
+static int upload_vec(RtContext* ctx, T** dptr, const void* src, size_t count)
+{
+    size_t bytes = count * sizeof(T);
+    HIP_TRY(ctx, hipMalloc(dptr, bytes ? bytes : sizeof(T)));
+    if (bytes) HIP_TRY(ctx, hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+extern "C" {
+
+int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const RtTriangle* triangles, int n_triangles,
+                    const RtBVHNode* nodes, int n_nodes, const RtSphere* spheres, int n_spheres)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (n_models < 0 || n_triangles < 0 || n_nodes < 0 || n_spheres < 0 || (n_models && !models) || (n_triangles && !triangles) ||
+        (n_nodes && !nodes) || (n_spheres && !spheres))
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_scene: bad pointer/count");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+    /* ---- validate + re-lay out the BVHs reachable from the models */
+    SceneBuilder sb;
+    sb.nodes = nodes;
+    sb.nNodes = n_nodes;
+    sb.nTris = n_triangles;
+    sb.pairOfFirstChild.assign((size_t)n_nodes + 1, -1);
+    std::vector<uint32_t> rootCodes(n_models);
+    for (int i = 0; i < n_models; i++) {
+        const RtModel& m = models[i];
+        if (m.nodeOffset < 0 || m.nodeOffset >= n_nodes || m.triOffset < 0 || m.triOffset > n_triangles)
+            return fail(ctx, RT_ERR_SCENE, "model %d: nodeOffset/triOffset out of range", i);
+        const RtBVHNode& root = nodes[m.nodeOffset];
+        if (root.triangleCount == 0)
+            return fail(ctx, RT_ERR_SCENE, "model %d: root node has triangleCount 0 (empty mesh) — undefined in the reference (RC:246)", i);
+        int height = 0;
+        if (!sb.convert(m.nodeOffset, m.triOffset, m.nodeOffset, &rootCodes[i], &height))
+            return fail(ctx, RT_ERR_SCENE, "model %d: %s", i, sb.error.c_str());
+        if (height > RT_MAX_BVH_DEPTH) return fail(ctx, RT_ERR_SCENE, "model %d: BVH depth %d > %d", i, height, RT_MAX_BVH_DEPTH);
+    }
+
+    /* ---- triangles: RC:190-192 are ray independent, pre-difference them (same fp32 ops) */
+    std::vector<DTri> dtris((size_t)n_triangles);
+    std::vector<DTriN> dnorms((size_t)n_triangles);
+    for (int i = 0; i < n_triangles; i++) {
+        const RtTriangle& t = triangles[i];
+        rt_f3 A = rt_v3(t.posA[0], t.posA[1], t.posA[2]);
+        rt_f3 B = rt_v3(t.posB[0], t.posB[1], t.posB[2]);
+        rt_f3 Cc = rt_v3(t.posC[0], t.posC[1], t.posC[2]);
+        rt_f3 ab = B - A, ac = Cc - A;
+        rt_f3 f = rt_cross(ab, ac);
+        DTri& d = dtris[i];
+        d.ax = A.x; d.ay = A.y; d.az = A.z;
+        d.abx = ab.x; d.aby = ab.y; d.abz = ab.z;
+        d.acx = ac.x; d.acy = ac.y; d.acz = ac.z;
+        d.fx = f.x; d.fy = f.y; d.fz = f.z;
+        memcpy(dnorms[i].n + 0, t.normA, 12);
+        memcpy(dnorms[i].n + 3, t.normB, 12);
+        memcpy(dnorms[i].n + 6, t.normC, 12);
+    }
+
+    std::vector<float> sph((size_t)n_spheres * 4);
+    std::vector<DMaterial> mats((size_t)n_spheres + n_models);
+    for (int i = 0; i < n_spheres; i++) {
+        memcpy(&sph[4 * i], spheres[i].centre, 12);
+        sph[4 * i + 3] = spheres[i].radius;
+        pack_material(spheres[i].material, mats[i]);
+    }
+    std::vector<DModel> dmodels(n_models);
+    for (int i = 0; i < n_models; i++) {
+        pack_model(models[i], rootCodes[i], dmodels[i]);
+        pack_material(models[i].material, mats[n_spheres + i]);
+    }
+
+    free_scene(ctx);
+    int rc;
+    if ((rc = upload_vec(ctx, &ctx->dSpheres, sph.data(), sph.size()))) return rc;
+    if ((rc = upload_vec(ctx, &ctx->dMaterials, mats.data(), mats.size()))) return rc;
+    if ((rc = upload_vec(ctx, &ctx->dModels, dmodels.data(), dmodels.size()))) return rc;
+    if ((rc = upload_vec(ctx, &ctx->dPairs, sb.pairs.data(), sb.pairs.size()))) return rc;
+    if ((rc = upload_vec(ctx, &ctx->dTris, dtris.data(), dtris.size()))) return rc;
+    if ((rc = upload_vec(ctx, &ctx->dNorms, dnorms.data(), dnorms.size()))) return rc;
+    if ((rc = upload_vec(ctx, &ctx->dBigLeaves, sb.bigLeaves.data(), sb.bigLeaves.size()))) return rc;
+    ctx->nSpheres = n_spheres;
+    ctx->nModels = n_models;
+    ctx->nTris = n_triangles;
+    ctx->nPairs = (int)sb.pairs.size();
+    ctx->hModels.assign(models, models + n_models);
+    ctx->hRootCodes = rootCodes;
+    ctx->haveScene = true;
+    return RT_OK;
+}
+
+int rt_update_models(RtContext* ctx, const RtModel* models, int n_models)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!ctx->haveScene) return fail(ctx, RT_ERR_STATE, "rt_update_models before rt_upload_scene");
+    if (n_models != ctx->nModels || (n_models && !models)) return fail(ctx, RT_ERR_INVALID_ARG, "rt_update_models: model count changed (%d != %d)", n_models, ctx->nModels);
+    if (n_models == 0) return RT_OK;
+    std::vector<DModel> dmodels(n_models);
+    std::vector<DMaterial> mats(n_models);
+    for (int i = 0; i < n_models; i++) {
+        if (models[i].nodeOffset != ctx->hModels[i].nodeOffset || models[i].triOffset != ctx->hModels[i].triOffset)
+            return fail(ctx, RT_ERR_INVALID_ARG, "rt_update_models: model %d changed its BVH offsets; re-upload the scene", i);
+        pack_model(models[i], ctx->hRootCodes[i], dmodels[i]);
+        pack_material(models[i].material, mats[i]);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->dModels, dmodels.data(), sizeof(DModel) * n_models, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->dMaterials + ctx->nSpheres, mats.data(), sizeof(DMaterial) * n_models, hipMemcpyHostToDevice));
+    ctx->hModels.assign(models, models + n_models);
+    return RT_OK;
+}
+
+int rt_update_spheres(RtContext* ctx, const RtSphere* spheres, int n_spheres)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!ctx->haveScene) return fail(ctx, RT_ERR_STATE, "rt_update_spheres before rt_upload_scene");
+    if (n_spheres != ctx->nSpheres || (n_spheres && !spheres)) return fail(ctx, RT_ERR_INVALID_ARG, "rt_update_spheres: sphere count changed");
+    if (n_spheres == 0) return RT_OK;
+    std::vector<float> sph((size_t)n_spheres * 4);
+    std::vector<DMaterial> mats(n_spheres);
+    for (int i = 0; i < n_spheres; i++) {
+        memcpy(&sph[4 * i], spheres[i].centre, 12);
+        sph[4 * i + 3] = spheres[i].radius;
+        pack_material(spheres[i].material, mats[i]);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->dSpheres, sph.data(), sph.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->dMaterials, mats.data(), sizeof(DMaterial) * n_spheres, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+int rt_set_params(RtContext* ctx, const RtParams* p)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!p) return fail(ctx, RT_ERR_INVALID_ARG, "rt_set_params: null params");
+    if (p->abi_version != RT_ABI_VERSION || p->struct_size != sizeof(RtParams))
+        return fail(ctx, RT_ERR_ABI_MISMATCH, "rt_set_params: abi_version %u / struct_size %u, library has %u / %zu", p->abi_version,
+                    p->struct_size, (unsigned)RT_ABI_VERSION, sizeof(RtParams));
+    ctx->params = *p;
+    ctx->frame = p->frame;
+    ctx->haveParams = true;
+    return RT_OK;
+}
+
+int rt_reset_accumulation(RtContext* ctx)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (ctx->W == 0) return fail(ctx, RT_ERR_STATE, "rt_reset_accumulation before rt_resize");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float* accum = ctx->boundAccum ? ctx->boundAccum : ctx->ownAccum;
+    size_t n = (size_t)ctx->localRows * ctx->W;
+    if (n) {
+        int blocks = (int)((n + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(rtk::rt_reset_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (float4*)accum, n);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    ctx->frame = 1; /* RCM:71 */
+    return RT_OK;
+}
+
+static int launch_frames(RtContext* ctx, int frame0, int nFrames)
+{
+    KArgs a;
+    memset(&a, 0, sizeof(a));
+    a.spheres = ctx->dSpheres;
+    a.materials = ctx->dMaterials;
+    a.models = ctx->dModels;
+    a.pairs = ctx->dPairs;
+    a.tris = ctx->dTris;
+    a.norms = ctx->dNorms;
+    a.bigLeaves = ctx->dBigLeaves;
+    a.nSpheres = ctx->nSpheres;
+    a.nModels = ctx->nModels;
+    a.frameRender = ctx->boundFrame ? ctx->boundFrame : ctx->ownFrame;
+    a.accumulated = ctx->boundAccum ? ctx->boundAccum : ctx->ownAccum;
+    a.W = (uint32_t)ctx->W;
+    a.H = (uint32_t)ctx->H;
+    a.localRows = ctx->localRows;
+    a.stripRows = ctx->stripRows;
+    a.partIndex = ctx->partIndex;
+    a.partCount = ctx->partCount;
+    a.tilesX = (ctx->W + 7) / 8;
+    a.tilesY = (ctx->localRows + 7) / 8;
+    const RtParams& p = ctx->params;
+    a.maxBounce = p.maxBounceCount;
+    a.spp = p.numRaysPerPixel;
+    a.frame0 = frame0;
+    a.nFrames = nFrames;
+    a.seed = p.renderSeed;
+    a.useSky = p.useSky;
+    a.accumulate = p.accumulate;
+    a.defocus = p.defocusStrength;
+    a.diverge = p.divergeStrength;
+    a.sunFocus = p.sunFocus;
+    a.sunIntensity = p.sunIntensity;
+    memcpy(a.sunColour, p.sunColour, 12);
+    memcpy(a.dirToSun, p.dirToSun, 12);
+    memcpy(a.viewParams, p.viewParams, 12);
+    memcpy(a.cam, p.camLocalToWorld, 64);
+    a.counters = ctx->dCounters;
+
+    int tiles = a.tilesX * a.tilesY;
+    if (tiles == 0) return RT_OK;
+    if (ctx->stats)
+        hipLaunchKernelGGL(rtk::rt_trace_kernel<true>, dim3(tiles), dim3(RT_WAVE), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(rtk::rt_trace_kernel<false>, dim3(tiles), dim3(RT_WAVE), 0, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->pixelFrames += (uint64_t)ctx->localRows * ctx->W * nFrames;
+    return RT_OK;
+}
+
+static int check_renderable(RtContext* ctx)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (ctx->W == 0) return fail(ctx, RT_ERR_STATE, "render before rt_resize");
+    if (!ctx->haveScene) return fail(ctx, RT_ERR_STATE, "render before rt_upload_scene");
+    if (!ctx->haveParams) return fail(ctx, RT_ERR_STATE, "render before rt_set_params");
+    if (ctx->params.numRaysPerPixel < 0) return fail(ctx, RT_ERR_INVALID_ARG, "numRaysPerPixel < 0");
+    return RT_OK;
+}
+
+int rt_render_frame(RtContext* ctx)
+{
+    int rc = check_renderable(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rc = launch_frames(ctx, ctx->frame, 1);
+    if (rc) return rc;
+    if (ctx->params.accumulate) ctx->frame++; /* RCM:94 */
+    return RT_OK;
+}
+
+int rt_render_frames(RtContext* ctx, int n)
+{
+    int rc = check_renderable(ctx);
+    if (rc) return rc;
+    if (n < 0) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render_frames: n < 0");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < n; i++) {
+        rc = launch_frames(ctx, ctx->frame, 1);
+        if (rc) return rc;
+        if (ctx->params.accumulate) ctx->frame++;
+    }
+    return RT_OK;
+}
+
+int rt_synchronize(RtContext* ctx)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    flush_timer(ctx);
+    return RT_OK;
+}
+
+int rt_get_frame(const RtContext* ctx) { return ctx ? ctx->frame : RT_ERR_INVALID_ARG; }
+
+int rt_timer_begin(RtContext* ctx)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    flush_timer(ctx);
+    if (ctx->timerState == 1) return fail(ctx, RT_ERR_STATE, "rt_timer_begin: timer already running");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(ctx->evStart, ctx->stream));
+    ctx->timerState = 1;
+    return RT_OK;
+}
+int rt_timer_end(RtContext* ctx)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (ctx->timerState != 1) return fail(ctx, RT_ERR_STATE, "rt_timer_end without rt_timer_begin");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(ctx->evStop, ctx->stream));
+    ctx->timerState = 2;
+    return RT_OK;
+}
+
+static int read_target(RtContext* ctx, const float* src, float* rgba, size_t bytes)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    size_t want = (size_t)ctx->localRows * ctx->W * 16;
+    if (!rgba || bytes != want) return fail(ctx, RT_ERR_INVALID_ARG, "read: need exactly %zu bytes, got %zu", want, bytes);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    flush_timer(ctx);
+    if (bytes) HIP_TRY(ctx, hipMemcpy(rgba, src, bytes, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+int rt_read_frame(RtContext* ctx, float* rgba, size_t bytes)
+{
+    return read_target(ctx, ctx ? (ctx->boundFrame ? ctx->boundFrame : ctx->ownFrame) : nullptr, rgba, bytes);
+}
+int rt_read_accumulated(RtContext* ctx, float* rgba, size_t bytes)
+{
+    return read_target(ctx, ctx ? (ctx->boundAccum ? ctx->boundAccum : ctx->ownAccum) : nullptr, rgba, bytes);
+}
+
+int rt_enable_stats(RtContext* ctx, int enabled)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    ctx->stats = enabled != 0;
+    return RT_OK;
+}
+
+int rt_reset_counters(RtContext* ctx)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    flush_timer(ctx);
+    HIP_TRY(ctx, hipMemset(ctx->dCounters, 0, sizeof(unsigned long long) * RT_COUNTER_SLOTS * RT_COUNTER_FIELDS));
+    ctx->pixelFrames = 0;
+    ctx->gpuMs = 0;
+    return RT_OK;
+}
+
+int rt_get_counters(RtContext* ctx, RtCounters* out)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!out) return fail(ctx, RT_ERR_INVALID_ARG, "rt_get_counters: null out");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    flush_timer(ctx);
+    std::vector<unsigned long long> h((size_t)RT_COUNTER_SLOTS * RT_COUNTER_FIELDS);
+    HIP_TRY(ctx, hipMemcpy(h.data(), ctx->dCounters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long sum[RT_COUNTER_FIELDS] = {0};
+    for (int s = 0; s < RT_COUNTER_SLOTS; s++)
+        for (int f = 0; f < RT_COUNTER_FIELDS; f++) sum[f] += h[(size_t)s * RT_COUNTER_FIELDS + f];
+    out->segments = sum[0];
+    out->innerSteps = sum[1];
+    out->leafSteps = sum[2];
+    out->triTests = sum[3];
+    out->sphereTests = sum[4];
+    out->modelVisits = sum[5];
+    out->pixelFrames = ctx->pixelFrames;
+    out->gpuMs = ctx->gpuMs;
+    return RT_OK;
+}
+
+} /* extern "C" */

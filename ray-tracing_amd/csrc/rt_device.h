@@ -1,0 +1,97 @@
+/*
+ * rt_device.h — HBM-resident scene layout and kernel argument block of
+ * libraytrace_hip.so (internal; the boundary layouts are in include/rt_abi.h).
+ *
+ * The boundary hands us the reference's structured buffers (72-B triangles,
+ * 32-B nodes, 224-B models).  rt_upload_scene re-lays them out once for the
+ * traversal kernel; results do not change because every derived value is
+ * computed with the same fp32 operation the reference's per-ray code performs
+ * (RayCommon.hlsl:190-192 are ray-independent):
+ *
+ *  DPair (64 B, 64-B aligned): both children of one inner node — the only
+ *      thing RayTriangleBVH (RC:262-282) reads per inner step — with each
+ *      child's (startIndex, triangleCount) pre-decoded into a 32-bit "code",
+ *      so a popped entry never re-reads its own node (reference: 96 B per
+ *      inner step; here: one aligned 64-B record).
+ *  DTri (48 B = 3 x float4): posA, edgeAB, edgeAC, cross(edgeAB, edgeAC).
+ *  DTriN (36 B): the three vertex normals, read once per segment for the
+ *      winning triangle only (the reference normalises a normal per test and
+ *      discards all but the winner's).
+ *  DModel (128 B): worldToLocal / localToWorld as three 4-float rows each,
+ *      root code, triangle base, cull flag — read with scalar loads.
+ *  DMaterial (96 B): RtMaterial padded to 6 x float4.
+ */
+#ifndef RT_DEVICE_H
+#define RT_DEVICE_H
+
+#include <stdint.h>
+
+#define RT_WAVE 64
+#define RT_STACK_DEPTH 34            /* >= RT_MAX_BVH_DEPTH + 2 */
+#define RT_COUNTER_SLOTS 1024        /* counters are spread over slots to avoid same-address atomics */
+#define RT_COUNTER_FIELDS 8
+
+/* node codes: bit31 = leaf.  leaf: [30:24] = triangle count (1..127), [23:0] = first
+ * triangle (relative to the model's triOffset); count field 0 = indirect, [23:0]
+ * indexes bigLeaves {start,count}.  inner: [30:0] = absolute DPair index. */
+#define RT_CODE_LEAF 0x80000000u
+#define RT_CODE_MAX_INLINE_COUNT 127
+#define RT_CODE_MAX_INLINE_START 0x00ffffffu
+
+struct DPair {
+    float aMin[3], aMax[3];
+    float bMin[3], bMax[3];
+    uint32_t codeA, codeB;
+    uint32_t pad[2];
+};
+struct DTri {
+    float ax, ay, az, abx;
+    float aby, abz, acx, acy;
+    float acz, fx, fy, fz;
+};
+struct DTriN {
+    float n[9];
+};
+struct DModel {
+    float w2l[12]; /* row r: m[r], m[4+r], m[8+r], m[12+r] of worldToLocal */
+    float l2w[12];
+    uint32_t rootCode;
+    int32_t triBase;
+    int32_t cullBackface; /* material.flag != GLASS (RC:355) */
+    int32_t pad[5];
+};
+struct DMaterial {
+    float diffuseCol[4], emissionCol[4], specularCol[4], absorption[4];
+    float absorptionStrength, emissionStrength, smoothness, specularProbability;
+    float ior;
+    int32_t flag;
+    int32_t pad[2];
+};
+
+struct KArgs {
+    /* scene */
+    const float* spheres;        /* nSpheres x (cx, cy, cz, r) */
+    const DMaterial* materials;  /* [0,nSpheres) spheres, then models */
+    const DModel* models;
+    const DPair* pairs;
+    const DTri* tris;
+    const DTriN* norms;
+    const uint32_t* bigLeaves;   /* pairs of (start, count) */
+    int32_t nSpheres, nModels;
+    /* render targets: rows owned by this context, packed */
+    float* frameRender;
+    float* accumulated;
+    uint32_t W, H;               /* GLOBAL resolution (uniform Resolution) */
+    int32_t localRows;
+    int32_t stripRows, partIndex, partCount;
+    int32_t tilesX, tilesY;
+    /* uniforms (RtParams) */
+    int32_t maxBounce, spp, frame0, nFrames, seed, useSky, accumulate;
+    float defocus, diverge, sunFocus, sunIntensity;
+    float sunColour[3], dirToSun[3], viewParams[3];
+    float cam[16];
+    /* counters: RT_COUNTER_SLOTS x RT_COUNTER_FIELDS u64 */
+    unsigned long long* counters;
+};
+
+#endif

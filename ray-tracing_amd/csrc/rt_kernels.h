@@ -1,0 +1,499 @@
+/*
+ * rt_kernels.h — the gfx950 path-tracing kernel of libraytrace_hip.so.
+ *
+ * Replaces the reference's HLSL kernels RayTrace / ResetAccumulated
+ * (Assets/Scripts/Tracer/RayCompute.compute:10-32) and everything they call in
+ * RayCommon.hlsl ("RC"), with the same per-pixel results:
+ *   - one wave64 = one 8x8 pixel tile (the reference's [numthreads(8,8,1)] group
+ *     happens to be exactly one CDNA wavefront);
+ *   - each lane owns one pixel and runs that pixel's serial RNG chain (quirk Q13);
+ *     instead of the reference's nested sample/bounce loops, a lane whose path
+ *     ends immediately starts its pixel's next sample (and next frame), so the
+ *     wave stays converged on the expensive part — the scene intersection —
+ *     while lanes sit at different samples/bounces;
+ *   - the per-ray BVH order (near child first, strict '<', RC:256,274-281) is
+ *     the reference's, so closest-hit ties resolve identically; the near child
+ *     stays in a register instead of being pushed and popped, the far child goes
+ *     to a per-lane stack in LDS laid out [level][lane] (bank = lane, conflict
+ *     free for ds_read/write_b32);
+ *   - spheres / models / uniforms are wave-uniform and come through scalar loads;
+ *   - no MFMA: branchy scalar fp32, there is no contraction to map.
+ *
+ * Arithmetic follows include/rt_math.h (strict fp32, no contraction) so the
+ * output is bit-identical to oracle/rt_oracle.cpp.
+ */
+#ifndef RT_KERNELS_H
+#define RT_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/rt_abi.h"
+#include "../../include/rt_math.h"
+#include "rt_device.h"
+
+namespace rtk {
+
+/* Scene constants (spheres, models) are indexed wave-uniformly and never written
+ * during a launch: reading them through the constant address space lets the
+ * compiler use scalar loads (s_load_dwordx4/x8 into SGPRs) instead of 64
+ * identical vector loads. */
+#define RT_CAS __attribute__((address_space(4)))
+
+/* v_min_f32 / v_max_f32 (IEEE minNum/maxNum: a NaN operand yields the other one,
+ * like HLSL).  They may differ from rt_min/rt_max only in the sign of a zero
+ * result, which the slab test below never observes (it only compares against 0
+ * and returns a literal 0). */
+__device__ __forceinline__ float hw_min(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float hw_max(float a, float b) { return __builtin_fmaxf(a, b); }
+
+/* RayBoundingBoxDst — RC:219-231 */
+__device__ __forceinline__ float box_dst(rt_f3 pos, rt_f3 invDir, const float* bmin, const float* bmax)
+{
+    float tminx = (bmin[0] - pos.x) * invDir.x, tmaxx = (bmax[0] - pos.x) * invDir.x;
+    float tminy = (bmin[1] - pos.y) * invDir.y, tmaxy = (bmax[1] - pos.y) * invDir.y;
+    float tminz = (bmin[2] - pos.z) * invDir.z, tmaxz = (bmax[2] - pos.z) * invDir.z;
+    float tNear = hw_max(hw_max(hw_min(tminx, tmaxx), hw_min(tminy, tmaxy)), hw_min(tminz, tmaxz));
+    float tFar = hw_min(hw_min(hw_max(tminx, tmaxx), hw_max(tminy, tmaxy)), hw_max(tminz, tmaxz));
+    bool hit = tFar >= tNear && tFar > 0.0f;
+    return hit ? (tNear > 0.0f ? tNear : 0.0f) : RT_INF;
+}
+
+struct SceneHit {
+    float dst;      /* closest so far (result.dst) */
+    int obj;        /* -1 none; [0,nSpheres) sphere; nSpheres + model index */
+    int tri;        /* absolute triangle index (models) */
+    float u, v, det;
+    bool backface;
+};
+
+struct Stats {
+    uint32_t inner, leaf, tri, sphere, model;
+};
+
+/* RandomValueNormalDistribution / RandomDirection — RC:141-157 */
+__device__ __forceinline__ float rand_normal(uint32_t* state)
+{
+    float theta = 2 * 3.1415926f * rt_random_value(state);
+    float rho = rt_sqrt(-2 * rt_log(rt_random_value(state)));
+    return rho * rt_cos(theta);
+}
+__device__ __forceinline__ rt_f3 rand_direction(uint32_t* state)
+{
+    float x = rand_normal(state);
+    float y = rand_normal(state);
+    float z = rand_normal(state);
+    return rt_normalize(rt_v3(x, y, z));
+}
+/* RandomPointInCircle — RC:159-164 (PI = 3.1415, RC:2) */
+__device__ __forceinline__ rt_f2 rand_circle(uint32_t* state)
+{
+    float angle = rt_random_value(state) * 2 * 3.1415f;
+    float c = rt_cos(angle), s = rt_sin(angle);
+    float r = rt_sqrt(rt_random_value(state));
+    rt_f2 o = {c * r, s * r};
+    return o;
+}
+
+/* GetEnvironmentLight — RC:167-183 (UseSky checked by the caller) */
+__device__ __forceinline__ rt_f3 environment_light(const KArgs& a, rt_f3 dir)
+{
+    float skyGradientT = rt_pow(rt_smoothstep(0.0f, 0.4f, dir.y), 0.35f);
+    float groundToSkyT = rt_smoothstep(-0.01f, 0.0f, dir.y);
+    rt_f3 skyGradient = rt_lerp3(rt_v3(1, 1, 1), rt_v3(0.08f, 0.37f, 0.73f), skyGradientT);
+    float s = 1000 * 1 / a.sunFocus;
+    rt_f3 toSun = rt_v3(a.dirToSun[0], a.dirToSun[1], a.dirToSun[2]);
+    float sun = rt_pow(rt_max(0.0f, rt_dot(dir, toSun)), s) * a.sunIntensity;
+    float gate = (groundToSkyT >= 1.0f) ? 1.0f : 0.0f;
+    return rt_lerp3(rt_v3(0.35f, 0.3f, 0.35f), skyGradient, groundToSkyT)
+           + sun * rt_v3(a.sunColour[0], a.sunColour[1], a.sunColour[2]) * gate;
+}
+
+/* CalculateReflectance — RC:383-405 */
+__device__ __forceinline__ float reflectance(rt_f3 inDir, rt_f3 normal, float iorA, float iorB)
+{
+    float refractRatio = iorA / iorB;
+    float cosAngleIn = -rt_dot(inDir, normal);
+    float sinSqr = refractRatio * refractRatio * (1 - cosAngleIn * cosAngleIn);
+    if (sinSqr >= 1) return 1.0f;
+    float cosRefr = rt_sqrt(1 - sinSqr);
+    float denomPerp = iorA * cosAngleIn + iorB * cosRefr;
+    float denomPar = iorA * cosAngleIn + iorB * cosRefr; /* RC:392 repeats RC:391 */
+    if (rt_min(denomPerp, denomPar) < 1E-8f) return 1.0f;
+    float rPerp = (iorA * cosAngleIn - iorB * cosRefr) / denomPerp;
+    rPerp *= rPerp;
+    float rPar = (iorB * cosAngleIn - iorA * cosRefr) / denomPar;
+    rPar *= rPar;
+    return (rPerp + rPar) / 2;
+}
+/* Refract — RC:408-417 */
+__device__ __forceinline__ rt_f3 refract_dir(rt_f3 inDir, rt_f3 normal, float iorA, float iorB)
+{
+    float refractRatio = iorA / iorB;
+    float cosAngleIn = -rt_dot(inDir, normal);
+    float sinSqr = refractRatio * refractRatio * (1 - cosAngleIn * cosAngleIn);
+    if (sinSqr > 1) return rt_v3s(0.0f);
+    return refractRatio * inDir + (refractRatio * cosAngleIn - rt_sqrt(1 - sinSqr)) * normal;
+}
+
+/* GetMaterialColour — RC:450-466 with mod2 RC:376-379 */
+__device__ __forceinline__ float mod2f(float x, float y) { return x - y * rt_floor(x / y); }
+__device__ __forceinline__ rt_f3 material_colour(const DMaterial& mat, rt_f3 pos, rt_f3 normal, bool isSpecular)
+{
+    rt_f3 col = rt_v3(mat.diffuseCol[0], mat.diffuseCol[1], mat.diffuseCol[2]);
+    if (mat.flag == RT_MATERIAL_CHECKERED) {
+        float px = pos.x, py = pos.z;
+        if (rt_abs(normal.x) > rt_abs(normal.y)) { px = pos.z; py = pos.y; }
+        if (rt_abs(normal.z) > rt_max(rt_abs(normal.x), rt_abs(normal.y))) { px = pos.x; py = pos.y; }
+        px *= 1.5f;
+        py *= 1.5f;
+        float cx = mod2f(rt_floor(px), 2.0f);
+        float cy = mod2f(rt_floor(py), 2.0f);
+        if (!(cx == cy)) col = rt_v3(mat.emissionCol[0], mat.emissionCol[1], mat.emissionCol[2]);
+    }
+    return rt_lerp3(col, rt_v3(mat.specularCol[0], mat.specularCol[1], mat.specularCol[2]), isSpecular ? 1.0f : 0.0f);
+}
+
+/* RayTriangle — RC:188-215 on a pre-differenced triangle. Updates the closest
+ * hit with the reference's strict '<' (RC:256). */
+__device__ __forceinline__ void tri_test(const DTri* __restrict__ tris, int triIndex, rt_f3 pos, rt_f3 dir, bool cull,
+                                         float& bestDst, int& bestTri, float& bu, float& bv, float& bdet)
+{
+    const float4* p = reinterpret_cast<const float4*>(tris + triIndex);
+    float4 q0 = p[0], q1 = p[1], q2 = p[2];
+    rt_f3 A = rt_v3(q0.x, q0.y, q0.z);
+    rt_f3 edgeAB = rt_v3(q0.w, q1.x, q1.y);
+    rt_f3 edgeAC = rt_v3(q1.z, q1.w, q2.x);
+    rt_f3 face = rt_v3(q2.y, q2.z, q2.w);
+    rt_f3 vertRayOffset = pos - A;
+    rt_f3 rayOffsetPerp = rt_cross(vertRayOffset, dir);
+    float determinant = -rt_dot(dir, face);
+    float invDet = 1 / determinant;
+    float dst = rt_dot(vertRayOffset, face) * invDet;
+    float u = rt_dot(edgeAC, rayOffsetPerp) * invDet;
+    float v = -rt_dot(edgeAB, rayOffsetPerp) * invDet;
+    float w = 1 - u - v;
+    bool keep = cull ? determinant >= 1E-8f : rt_abs(determinant) >= 1E-8f;
+    bool didHit = keep && dst > 0 && u >= 0 && v >= 0 && w >= 0;
+    if (didHit && dst < bestDst) {
+        bestDst = dst;
+        bestTri = triIndex;
+        bu = u;
+        bv = v;
+        bdet = determinant;
+    }
+}
+
+/* RayTriangleBVH — RC:234-287 for one model, one ray per lane. */
+template <bool STATS>
+__device__ __forceinline__ void traverse_model(const KArgs& a, uint32_t rootCode, int triBase, bool cull, rt_f3 pos, rt_f3 dir,
+                                               rt_f3 invDir, uint32_t* stackBase /* &s_stack[0][lane] */, float& bestDst,
+                                               int& bestTri, float& bu, float& bv, float& bdet, Stats& st)
+{
+    const DPair* __restrict__ pairs = a.pairs;
+    const DTri* __restrict__ tris = a.tris;
+    uint32_t cur = rootCode;
+    int sp = 0;
+    for (;;) {
+        if (cur & RT_CODE_LEAF) {
+            uint32_t count = (cur >> 24) & 0x7fu;
+            uint32_t start = cur & RT_CODE_MAX_INLINE_START;
+            if (count == 0) { /* indirect (huge leaf) */
+                count = a.bigLeaves[2 * start + 1];
+                start = a.bigLeaves[2 * start];
+            }
+            if (STATS) { st.leaf++; st.tri += count; }
+            int first = triBase + (int)start;
+            for (uint32_t i = 0; i < count; i++) tri_test(tris, first + (int)i, pos, dir, cull, bestDst, bestTri, bu, bv, bdet);
+            if (sp == 0) break;
+            cur = stackBase[(--sp) * RT_WAVE];
+        } else {
+            if (STATS) st.inner++;
+            const DPair* pr = pairs + cur;
+            const float4* q = reinterpret_cast<const float4*>(pr);
+            float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            float aMin[3] = {q0.x, q0.y, q0.z}, aMax[3] = {q0.w, q1.x, q1.y};
+            float bMin[3] = {q1.z, q1.w, q2.x}, bMax[3] = {q2.y, q2.z, q2.w};
+            uint32_t codeA = __float_as_uint(q3.x), codeB = __float_as_uint(q3.y);
+            float dstA = box_dst(pos, invDir, aMin, aMax);
+            float dstB = box_dst(pos, invDir, bMin, bMax);
+            bool isNearestA = dstA <= dstB;
+            float dstNear = isNearestA ? dstA : dstB;
+            float dstFar = isNearestA ? dstB : dstA;
+            uint32_t codeNear = isNearestA ? codeA : codeB;
+            uint32_t codeFar = isNearestA ? codeB : codeA;
+            /* RC:280-281: push far, then near; the next pop is the near child, so it
+             * stays in `cur`.  dstNear <= dstFar, so far-pushed implies near-pushed. */
+            if (dstNear < bestDst) {
+                if (dstFar < bestDst) { stackBase[sp * RT_WAVE] = codeFar; sp++; }
+                cur = codeNear;
+            } else {
+                if (sp == 0) break;
+                cur = stackBase[(--sp) * RT_WAVE];
+            }
+        }
+    }
+}
+
+/* CalculateRayCollision — RC:335-374 plus the sphere buffer hooked at RC:341. */
+template <bool STATS>
+__device__ __forceinline__ void intersect_scene(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, SceneHit& h, Stats& st)
+{
+    h.dst = RT_INF;
+    h.obj = -1;
+    h.tri = -1;
+    h.u = h.v = h.det = 0.0f;
+    h.backface = false;
+
+    /* RaySphere — RC:289-332 */
+    const RT_CAS float* sph = (const RT_CAS float*)a.spheres;
+    for (int s = 0; s < a.nSpheres; s++) {
+        rt_f3 centre = rt_v3(sph[4 * s + 0], sph[4 * s + 1], sph[4 * s + 2]);
+        float radius = sph[4 * s + 3];
+        rt_f3 off = rpos - centre;
+        float qa = rt_dot(rdir, rdir);
+        float qb = 2 * rt_dot(off, rdir);
+        float qc = rt_dot(off, off) - radius * radius;
+        float disc = qb * qb - 4 * qa * qc;
+        if (disc >= 0) {
+            float sq = rt_sqrt(disc);
+            float dstNear = rt_max(0.0f, (-qb - sq) / (2 * qa));
+            float dstFar = (-qb + sq) / (2 * qa);
+            if (dstFar >= 0) {
+                bool inside = dstNear == 0;
+                float d = inside ? dstFar : dstNear;
+                if (d < h.dst) {
+                    h.dst = d;
+                    h.obj = s;
+                    h.backface = inside;
+                }
+            }
+        }
+    }
+    if (STATS) st.sphere += (uint32_t)a.nSpheres;
+
+    const RT_CAS DModel* models = (const RT_CAS DModel*)a.models;
+    for (int m = 0; m < a.nModels; m++) {
+        const RT_CAS DModel& M = models[m];
+        /* RC:351-353 */
+        rt_f3 lpos = rt_v3(M.w2l[0] * rpos.x + M.w2l[1] * rpos.y + M.w2l[2] * rpos.z + M.w2l[3] * 1.0f,
+                           M.w2l[4] * rpos.x + M.w2l[5] * rpos.y + M.w2l[6] * rpos.z + M.w2l[7] * 1.0f,
+                           M.w2l[8] * rpos.x + M.w2l[9] * rpos.y + M.w2l[10] * rpos.z + M.w2l[11] * 1.0f);
+        rt_f3 ldir = rt_v3(M.w2l[0] * rdir.x + M.w2l[1] * rdir.y + M.w2l[2] * rdir.z + M.w2l[3] * 0.0f,
+                           M.w2l[4] * rdir.x + M.w2l[5] * rdir.y + M.w2l[6] * rdir.z + M.w2l[7] * 0.0f,
+                           M.w2l[8] * rdir.x + M.w2l[9] * rdir.y + M.w2l[10] * rdir.z + M.w2l[11] * 0.0f);
+        rt_f3 linv = rt_v3(1 / ldir.x, 1 / ldir.y, 1 / ldir.z);
+        float best = h.dst;
+        int bestTri = -1;
+        float bu = 0, bv = 0, bdet = 0;
+        traverse_model<STATS>(a, M.rootCode, M.triBase, M.cullBackface != 0, lpos, ldir, linv, stackBase, best, bestTri, bu, bv,
+                              bdet, st);
+        if (bestTri >= 0) { /* <=> hit.dst < result.dst (RC:362) */
+            h.dst = best;
+            h.obj = a.nSpheres + m;
+            h.tri = bestTri;
+            h.u = bu;
+            h.v = bv;
+            h.det = bdet;
+            h.backface = bdet < 0;
+        }
+    }
+    if (STATS) st.model += (uint32_t)a.nModels;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(RT_WAVE) rt_trace_kernel(const KArgs a)
+{
+    __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_WAVE];
+    const int lane = threadIdx.x;
+    uint32_t* stackBase = &s_stack[lane];
+
+    const int tile = blockIdx.x;
+    const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+    const int x = tx * 8 + (lane & 7);
+    const int lrow = ty * 8 + (lane >> 3);
+    bool laneDone = !(x < (int)a.W && lrow < a.localRows);
+    /* cyclic strips: local strip ls is global strip ls*partCount + partIndex */
+    const int ls = lrow / a.stripRows;
+    const int y = (ls * a.partCount + a.partIndex) * a.stripRows + (lrow - ls * a.stripRows);
+
+    /* RCC:15 */
+    const float uvx = (float)(uint32_t)x / ((float)a.W - 1.0f);
+    const float uvy = (float)(uint32_t)y / ((float)a.H - 1.0f);
+    /* RC:547-558 */
+    const rt_f3 camOrigin = rt_v3(a.cam[0] * 0.0f + a.cam[4] * 0.0f + a.cam[8] * 0.0f + a.cam[12] * 1.0f,
+                                  a.cam[1] * 0.0f + a.cam[5] * 0.0f + a.cam[9] * 0.0f + a.cam[13] * 1.0f,
+                                  a.cam[2] * 0.0f + a.cam[6] * 0.0f + a.cam[10] * 0.0f + a.cam[14] * 1.0f);
+    const uint32_t pixelCoordX = (uint32_t)(uvx * (float)a.W);
+    const uint32_t pixelCoordY = (uint32_t)(uvy * (float)a.H);
+    const uint32_t pixelIndex = pixelCoordY * a.W + pixelCoordX;
+    const rt_f3 fpl = rt_v3(uvx - 0.5f, uvy - 0.5f, 1.0f) * rt_v3(a.viewParams[0], a.viewParams[1], a.viewParams[2]);
+    const rt_f3 focusPoint = rt_mul_point(a.cam, fpl, 1.0f);
+    const rt_f3 camRight = rt_v3(a.cam[0], a.cam[1], a.cam[2]);
+    const rt_f3 camUp = rt_v3(a.cam[4], a.cam[5], a.cam[6]);
+    const float numPixelsX = (float)a.W;
+
+    const size_t pixOff = ((size_t)lrow * a.W + (size_t)x) * 4;
+
+    int frame = a.frame0;
+    const int frameEnd = a.frame0 + a.nFrames;
+    uint32_t rng = pixelIndex + (uint32_t)frame * 719393u + (uint32_t)a.seed; /* RC:552 */
+    int sample = 0;
+    rt_f3 totalIncoming = rt_v3s(0.0f);
+
+    bool pathActive = false;
+    int bounce = 0;
+    rt_f3 rpos = rt_v3s(0.0f), rdir = rt_v3s(0.0f), transmittance = rt_v3s(0.0f), pathLight = rt_v3s(0.0f);
+    uint32_t segments = 0;
+    Stats st = {0, 0, 0, 0, 0};
+    if (a.nFrames <= 0) laneDone = true;
+
+    while (!laneDone) {
+        if (!pathActive) {
+            if (sample == a.spp) {
+                /* RC:581 + RCC:18-23: finish this frame of this pixel */
+                rt_f3 col = totalIncoming / (float)a.spp;
+                if (frame == frameEnd - 1) {
+                    float4 o = make_float4(col.x, col.y, col.z, 1.0f);
+                    *reinterpret_cast<float4*>(a.frameRender + pixOff) = o;
+                }
+                if (a.accumulate) {
+                    float4 acc = *reinterpret_cast<float4*>(a.accumulated + pixOff);
+                    acc.x += col.x;
+                    acc.y += col.y;
+                    acc.z += col.z;
+                    acc.w += 1.0f;
+                    *reinterpret_cast<float4*>(a.accumulated + pixOff) = acc;
+                }
+                frame++;
+                if (frame == frameEnd) {
+                    laneDone = true;
+                } else {
+                    rng = pixelIndex + (uint32_t)frame * 719393u + (uint32_t)a.seed;
+                    sample = 0;
+                    totalIncoming = rt_v3s(0.0f);
+                }
+            }
+            if (!laneDone && sample < a.spp) {
+                /* RC:565-576: next camera ray of this pixel */
+                rt_f2 dj = rand_circle(&rng);
+                rt_f3 rayOrigin = camOrigin + camRight * (dj.x * a.defocus / numPixelsX) + camUp * (dj.y * a.defocus / numPixelsX);
+                rt_f2 jj = rand_circle(&rng);
+                rt_f3 jfp = focusPoint + camRight * (jj.x * a.diverge / numPixelsX) + camUp * (jj.y * a.diverge / numPixelsX);
+                rpos = rayOrigin;
+                rdir = rt_normalize(jfp - rayOrigin);
+                transmittance = rt_v3s(1.0f);
+                pathLight = rt_v3s(0.0f);
+                bounce = 0;
+                pathActive = true;
+                sample++;
+            }
+        }
+        if (pathActive) {
+            /* one iteration of Trace's bounce loop — RC:485-539 */
+            SceneHit h;
+            intersect_scene<STATS>(a, rpos, rdir, stackBase, h, st);
+            segments++;
+            bool endPath = false;
+            if (h.obj < 0) {
+                if (a.useSky) pathLight = pathLight + transmittance * environment_light(a, rdir);
+                endPath = true;
+            } else {
+                /* resolve the winner: position, normal, material */
+                rt_f3 hpos = rpos + rdir * h.dst;
+                rt_f3 normal;
+                if (h.obj < a.nSpheres) {
+                    const float* sp4 = a.spheres + 4 * h.obj;
+                    rt_f3 centre = rt_v3(sp4[0], sp4[1], sp4[2]);
+                    normal = rt_normalize(hpos - centre) * (h.backface ? -1.0f : 1.0f);
+                } else {
+                    const DModel& M = a.models[h.obj - a.nSpheres];
+                    const DTriN& N = a.norms[h.tri];
+                    float w = 1 - h.u - h.v;
+                    rt_f3 sn = rt_normalize(rt_v3(N.n[0], N.n[1], N.n[2]) * w + rt_v3(N.n[3], N.n[4], N.n[5]) * h.u
+                                            + rt_v3(N.n[6], N.n[7], N.n[8]) * h.v);
+                    rt_f3 ln = sn * rt_sign(h.det);
+                    /* RC:367 (quirk Q10: localToWorld, not inverse-transpose) */
+                    normal = rt_normalize(rt_v3(M.l2w[0] * ln.x + M.l2w[1] * ln.y + M.l2w[2] * ln.z + M.l2w[3] * 0.0f,
+                                                M.l2w[4] * ln.x + M.l2w[5] * ln.y + M.l2w[6] * ln.z + M.l2w[7] * 0.0f,
+                                                M.l2w[8] * ln.x + M.l2w[9] * ln.y + M.l2w[10] * ln.z + M.l2w[11] * 0.0f));
+                }
+                const DMaterial mat = a.materials[h.obj];
+
+                if (mat.flag == RT_MATERIAL_GLASS) { /* RC:499-518 */
+                    if (h.backface) {
+                        rt_f3 e = ((-h.dst) * rt_v3(mat.absorption[0], mat.absorption[1], mat.absorption[2])) * mat.absorptionStrength;
+                        transmittance = transmittance * rt_v3(rt_exp(e.x), rt_exp(e.y), rt_exp(e.z));
+                    }
+                    float iorCurrent = h.backface ? mat.ior : 1.0f;
+                    float iorNext = h.backface ? 1.0f : mat.ior;
+                    rt_f3 reflectDir = rdir - (2 * rt_dot(rdir, normal)) * normal; /* RC:419-422 */
+                    rt_f3 refractDir = refract_dir(rdir, normal, iorCurrent, iorNext);
+                    float reflectWeight = reflectance(rdir, normal, iorCurrent, iorNext);
+                    rt_f3 diffuseDir = rt_normalize(normal + rand_direction(&rng));
+                    reflectDir = rt_normalize(rt_lerp3(diffuseDir, reflectDir, mat.specularProbability));
+                    refractDir = rt_normalize(rt_lerp3(-diffuseDir, refractDir, mat.smoothness));
+                    bool followReflection = rt_random_value(&rng) <= reflectWeight;
+                    rdir = followReflection ? reflectDir : refractDir;
+                    rpos = hpos + (0.001f * normal) * rt_sign(rt_dot(normal, rdir));
+                } else { /* RC:519-533 */
+                    bool isSpecular = mat.specularProbability >= rt_random_value(&rng);
+                    rpos = hpos + (normal * 0.001f);
+                    rt_f3 diffuseDir = rt_normalize(normal + rand_direction(&rng));
+                    rt_f3 specularDir = rt_reflect(rdir, normal);
+                    rdir = rt_normalize(rt_lerp3(diffuseDir, specularDir, mat.smoothness * (isSpecular ? 1.0f : 0.0f)));
+                    rt_f3 emitted = rt_v3(mat.emissionCol[0], mat.emissionCol[1], mat.emissionCol[2]) * mat.emissionStrength;
+                    pathLight = pathLight + emitted * transmittance;
+                    transmittance = transmittance * material_colour(mat, hpos, normal, isSpecular);
+                }
+                /* RC:535-538 Russian roulette */
+                float p = rt_max(transmittance.x, rt_max(transmittance.y, transmittance.z));
+                if (rt_random_value(&rng) >= p) {
+                    endPath = true;
+                } else {
+                    transmittance = transmittance * (1 / p);
+                    bounce++;
+                    if (bounce > a.maxBounce) endPath = true; /* RC:485: i <= MaxBounceCount */
+                }
+            }
+            if (endPath) {
+                totalIncoming = totalIncoming + pathLight; /* RC:578 */
+                pathActive = false;
+            }
+        }
+    }
+
+    /* exact work counters: one set of atomics per wave, spread over slots */
+    uint32_t segSum = wave_sum(segments);
+    unsigned long long* slot = a.counters + (size_t)(blockIdx.x % RT_COUNTER_SLOTS) * RT_COUNTER_FIELDS;
+    if (STATS) {
+        uint32_t in = wave_sum(st.inner), lf = wave_sum(st.leaf), tr = wave_sum(st.tri), sp = wave_sum(st.sphere), md = wave_sum(st.model);
+        if (lane == 0) {
+            atomicAdd(slot + 0, (unsigned long long)segSum);
+            atomicAdd(slot + 1, (unsigned long long)in);
+            atomicAdd(slot + 2, (unsigned long long)lf);
+            atomicAdd(slot + 3, (unsigned long long)tr);
+            atomicAdd(slot + 4, (unsigned long long)sp);
+            atomicAdd(slot + 5, (unsigned long long)md);
+        }
+    } else if (lane == 0) {
+        atomicAdd(slot + 0, (unsigned long long)segSum);
+    }
+}
+
+/* ResetAccumulated — RCC:26-32 */
+__global__ void rt_reset_kernel(float4* accum, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) accum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+} // namespace rtk
+
+#endif
