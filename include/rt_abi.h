@@ -251,6 +251,15 @@ int rt_build_bvh(const float* verts, const float* normals, int n_verts,
 /* RCM:183-190 UpdateCameraParams: fills viewParams from (fovDeg, aspect, focusDist). */
 int rt_camera_view_params(float fov_deg, float aspect, float focus_distance, float out_view_params[3]);
 
+/* ---- test hooks: the kernel's device functions on caller-supplied inputs ---- */
+/* CalculateRayCollision (RC:335-374) for n world rays (origins/dirs: n*3 floats,
+ * host memory). out10 per ray: didHit, isBackface, dst, normal.xyz, pos.xyz,
+ * material.flag. Synchronous. */
+int rt_debug_intersect(RtContext* ctx, const float* origins, const float* dirs, int n, float* out10);
+/* Device evaluation of the include/rt_math.h primitives over host arrays.
+ * op: 0 log, 1 exp, 2 sin, 3 cos, 4 sqrt, 5 pow(x,y), 6 x/y, 7 smoothstep(0,y,x). */
+int rt_debug_math_eval(RtContext* ctx, int op, const float* x, const float* y, float* out, int n);
+
 /* Library identification: returns "raytrace_hip gfx950 abi=<n>" */
 const char* rt_version(void);
 

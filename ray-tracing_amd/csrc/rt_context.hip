@@ -535,9 +535,8 @@ int rt_reset_accumulation(RtContext* ctx)
     return RT_OK;
 }
 
-static int launch_frames(RtContext* ctx, int frame0, int nFrames)
+static void fill_args(RtContext* ctx, int frame0, int nFrames, KArgs& a)
 {
-    KArgs a;
     memset(&a, 0, sizeof(a));
     a.spheres = ctx->dSpheres;
     a.materials = ctx->dMaterials;
@@ -575,7 +574,12 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
     memcpy(a.viewParams, p.viewParams, 12);
     memcpy(a.cam, p.camLocalToWorld, 64);
     a.counters = ctx->dCounters;
+}
 
+static int launch_frames(RtContext* ctx, int frame0, int nFrames)
+{
+    KArgs a;
+    fill_args(ctx, frame0, nFrames, a);
     int tiles = a.tilesX * a.tilesY;
     if (tiles == 0) return RT_OK;
     if (ctx->stats)
@@ -711,6 +715,50 @@ int rt_get_counters(RtContext* ctx, RtCounters* out)
     out->modelVisits = sum[5];
     out->pixelFrames = ctx->pixelFrames;
     out->gpuMs = ctx->gpuMs;
+    return RT_OK;
+}
+
+/* ---- test hooks ------------------------------------------------------------ */
+int rt_debug_intersect(RtContext* ctx, const float* origins, const float* dirs, int n, float* out10)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!ctx->haveScene) return fail(ctx, RT_ERR_STATE, "rt_debug_intersect before rt_upload_scene");
+    if (n < 0 || (n && (!origins || !dirs || !out10))) return fail(ctx, RT_ERR_INVALID_ARG, "rt_debug_intersect: bad arguments");
+    if (n == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *dO = nullptr, *dD = nullptr, *dR = nullptr;
+    HIP_TRY(ctx, hipMalloc(&dO, (size_t)n * 12));
+    HIP_TRY(ctx, hipMalloc(&dD, (size_t)n * 12));
+    HIP_TRY(ctx, hipMalloc(&dR, (size_t)n * 40));
+    HIP_TRY(ctx, hipMemcpy(dO, origins, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dD, dirs, (size_t)n * 12, hipMemcpyHostToDevice));
+    KArgs a;
+    fill_args(ctx, 1, 1, a);
+    hipLaunchKernelGGL(rtk::rt_debug_intersect_kernel, dim3((n + RT_WAVE - 1) / RT_WAVE), dim3(RT_WAVE), 0, ctx->stream, a, dO, dD, n, dR);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out10, dR, (size_t)n * 40, hipMemcpyDeviceToHost));
+    hipFree(dO); hipFree(dD); hipFree(dR);
+    return RT_OK;
+}
+
+int rt_debug_math_eval(RtContext* ctx, int op, const float* x, const float* y, float* out, int n)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (n < 0 || (n && (!x || !y || !out))) return fail(ctx, RT_ERR_INVALID_ARG, "rt_debug_math_eval: bad arguments");
+    if (n == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *dX = nullptr, *dY = nullptr, *dR = nullptr;
+    HIP_TRY(ctx, hipMalloc(&dX, (size_t)n * 4));
+    HIP_TRY(ctx, hipMalloc(&dY, (size_t)n * 4));
+    HIP_TRY(ctx, hipMalloc(&dR, (size_t)n * 4));
+    HIP_TRY(ctx, hipMemcpy(dX, x, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dY, y, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rtk::rt_debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, op, dX, dY, dR, n);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, dR, (size_t)n * 4, hipMemcpyDeviceToHost));
+    hipFree(dX); hipFree(dY); hipFree(dR);
     return RT_OK;
 }
 

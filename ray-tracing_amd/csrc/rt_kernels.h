@@ -300,6 +300,28 @@ __device__ __forceinline__ void intersect_scene(const KArgs& a, rt_f3 rpos, rt_f
     if (STATS) st.model += (uint32_t)a.nModels;
 }
 
+/* Position and world normal of the winning hit: RC:319-320 (sphere) or RC:208-209 +
+ * RC:367-368 (triangle; quirk Q10: localToWorld, not its inverse transpose). */
+__device__ __forceinline__ void resolve_hit(const KArgs& a, rt_f3 rpos, rt_f3 rdir, const SceneHit& h, rt_f3& hpos, rt_f3& normal)
+{
+    hpos = rpos + rdir * h.dst;
+    if (h.obj < a.nSpheres) {
+        const float* sp4 = a.spheres + 4 * h.obj;
+        rt_f3 centre = rt_v3(sp4[0], sp4[1], sp4[2]);
+        normal = rt_normalize(hpos - centre) * (h.backface ? -1.0f : 1.0f);
+    } else {
+        const DModel& M = a.models[h.obj - a.nSpheres];
+        const DTriN& N = a.norms[h.tri];
+        float w = 1 - h.u - h.v;
+        rt_f3 sn = rt_normalize(rt_v3(N.n[0], N.n[1], N.n[2]) * w + rt_v3(N.n[3], N.n[4], N.n[5]) * h.u
+                                + rt_v3(N.n[6], N.n[7], N.n[8]) * h.v);
+        rt_f3 ln = sn * rt_sign(h.det);
+        normal = rt_normalize(rt_v3(M.l2w[0] * ln.x + M.l2w[1] * ln.y + M.l2w[2] * ln.z + M.l2w[3] * 0.0f,
+                                    M.l2w[4] * ln.x + M.l2w[5] * ln.y + M.l2w[6] * ln.z + M.l2w[7] * 0.0f,
+                                    M.l2w[8] * ln.x + M.l2w[9] * ln.y + M.l2w[10] * ln.z + M.l2w[11] * 0.0f));
+    }
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -405,24 +427,8 @@ __global__ void __launch_bounds__(RT_WAVE) rt_trace_kernel(const KArgs a)
                 endPath = true;
             } else {
                 /* resolve the winner: position, normal, material */
-                rt_f3 hpos = rpos + rdir * h.dst;
-                rt_f3 normal;
-                if (h.obj < a.nSpheres) {
-                    const float* sp4 = a.spheres + 4 * h.obj;
-                    rt_f3 centre = rt_v3(sp4[0], sp4[1], sp4[2]);
-                    normal = rt_normalize(hpos - centre) * (h.backface ? -1.0f : 1.0f);
-                } else {
-                    const DModel& M = a.models[h.obj - a.nSpheres];
-                    const DTriN& N = a.norms[h.tri];
-                    float w = 1 - h.u - h.v;
-                    rt_f3 sn = rt_normalize(rt_v3(N.n[0], N.n[1], N.n[2]) * w + rt_v3(N.n[3], N.n[4], N.n[5]) * h.u
-                                            + rt_v3(N.n[6], N.n[7], N.n[8]) * h.v);
-                    rt_f3 ln = sn * rt_sign(h.det);
-                    /* RC:367 (quirk Q10: localToWorld, not inverse-transpose) */
-                    normal = rt_normalize(rt_v3(M.l2w[0] * ln.x + M.l2w[1] * ln.y + M.l2w[2] * ln.z + M.l2w[3] * 0.0f,
-                                                M.l2w[4] * ln.x + M.l2w[5] * ln.y + M.l2w[6] * ln.z + M.l2w[7] * 0.0f,
-                                                M.l2w[8] * ln.x + M.l2w[9] * ln.y + M.l2w[10] * ln.z + M.l2w[11] * 0.0f));
-                }
+                rt_f3 hpos, normal;
+                resolve_hit(a, rpos, rdir, h, hpos, normal);
                 const DMaterial mat = a.materials[h.obj];
 
                 if (mat.flag == RT_MATERIAL_GLASS) { /* RC:499-518 */
@@ -484,6 +490,49 @@ __global__ void __launch_bounds__(RT_WAVE) rt_trace_kernel(const KArgs a)
     } else if (lane == 0) {
         atomicAdd(slot + 0, (unsigned long long)segSum);
     }
+}
+
+/* ---- test hooks (rt_debug_*): the same device functions, one ray / value per lane */
+__global__ void __launch_bounds__(RT_WAVE) rt_debug_intersect_kernel(const KArgs a, const float* origins, const float* dirs, int n, float* out)
+{
+    __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_WAVE];
+    int i = blockIdx.x * RT_WAVE + threadIdx.x;
+    if (i >= n) return;
+    rt_f3 o = rt_v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
+    rt_f3 d = rt_v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+    SceneHit h;
+    Stats st = {0, 0, 0, 0, 0};
+    intersect_scene<false>(a, o, d, &s_stack[threadIdx.x], h, st);
+    float* r = out + 10 * i;
+    for (int k = 0; k < 10; k++) r[k] = 0.0f;
+    r[2] = h.dst;
+    if (h.obj >= 0) {
+        rt_f3 hpos, normal;
+        resolve_hit(a, o, d, h, hpos, normal);
+        r[0] = 1.0f;
+        r[1] = h.backface ? 1.0f : 0.0f;
+        r[3] = normal.x; r[4] = normal.y; r[5] = normal.z;
+        r[6] = hpos.x; r[7] = hpos.y; r[8] = hpos.z;
+        r[9] = (float)a.materials[h.obj].flag;
+    }
+}
+/* op codes as oracle_math_eval: 0 log 1 exp 2 sin 3 cos 4 sqrt 5 pow 6 div 7 smoothstep(0,y,x) */
+__global__ void rt_debug_math_kernel(int op, const float* x, const float* y, float* out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = 0.0f;
+    switch (op) {
+    case 0: r = rt_log(x[i]); break;
+    case 1: r = rt_exp(x[i]); break;
+    case 2: r = rt_sin(x[i]); break;
+    case 3: r = rt_cos(x[i]); break;
+    case 4: r = rt_sqrt(x[i]); break;
+    case 5: r = rt_pow(x[i], y[i]); break;
+    case 6: r = x[i] / y[i]; break;
+    case 7: r = rt_smoothstep(0.0f, y[i], x[i]); break;
+    }
+    out[i] = r;
 }
 
 /* ResetAccumulated — RCC:26-32 */

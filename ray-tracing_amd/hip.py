@@ -20,6 +20,7 @@ ABI_SYMBOLS = [
     "rt_update_spheres", "rt_set_params", "rt_reset_accumulation", "rt_render_frame", "rt_render_frames",
     "rt_synchronize", "rt_get_frame", "rt_read_frame", "rt_read_accumulated", "rt_timer_begin", "rt_timer_end",
     "rt_enable_stats", "rt_reset_counters", "rt_get_counters", "rt_build_bvh", "rt_camera_view_params", "rt_version",
+    "rt_debug_intersect", "rt_debug_math_eval",
 ]
 
 
@@ -36,6 +37,8 @@ class HipApi(abi.CApi):
         "timer_begin": (C.c_int, [C.c_void_p]),
         "timer_end": (C.c_int, [C.c_void_p]),
         "enable_stats": (C.c_int, [C.c_void_p, C.c_int]),
+        "debug_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+        "debug_math_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     }
 
     def __init__(self, path=LIB_PATH):
@@ -91,6 +94,20 @@ class HipTracer(abi.Tracer):
 
     def enable_stats(self, on=True):
         self._check(self.api.enable_stats(self.h, 1 if on else 0))
+
+    def debug_intersect(self, origins, dirs):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros((len(o), 10), dtype=np.float32)
+        self._check(self.api.debug_intersect(self.h, o.ctypes.data, d.ctypes.data, len(o), out.ctypes.data))
+        return out
+
+    def debug_math_eval(self, op, x, y=None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.ascontiguousarray(np.zeros_like(x) if y is None else y, dtype=np.float32)
+        out = np.empty_like(x)
+        self._check(self.api.debug_math_eval(self.h, int(op), x.ctypes.data, y.ctypes.data, out.ctypes.data, len(x)))
+        return out
 
 
 _api = None

@@ -1,0 +1,113 @@
+"""BVH: the product's host builder (rt_build_bvh) emits exactly the tree of the
+literal restatement of BVH.cs in the oracle, and the oracle's traversal finds the
+same closest hit as brute force over all triangles (property test)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def both(api, orc, mesh, quality):
+    a = api.build_bvh_arrays(mesh.vertices, mesh.normals, mesh.triangles, quality)
+    b = orc.build_bvh_arrays(mesh.vertices, mesh.normals, mesh.triangles, quality)
+    return a, b
+
+
+def mesh_cases(pkg):
+    m = pkg.meshes
+    rng = np.random.default_rng(7)
+    # triangle soup: overlapping random triangles (ragged leaves, SAH refusing splits)
+    v = rng.uniform(-1, 1, (300, 3)).astype(np.float32)
+    soup = m.Mesh(v, np.tile([[0, 1, 0]], (300, 1)), rng.integers(0, 300, 3 * 500).astype(np.int32), "soup")
+    # degenerate: every triangle identical (all centroids equal -> single leaf > 127 triangles)
+    same = m.Mesh(v[:3], np.tile([[0, 1, 0]], (3, 1)), np.tile([0, 1, 2], 200).astype(np.int32), "same")
+    # flat mesh in the y=0 plane (a zero-size axis: NaN in CeilToInt(axisSize/maxAxis*K) cannot occur, 0 can)
+    flat_v = np.stack([rng.uniform(-1, 1, 200), np.zeros(200), rng.uniform(-1, 1, 200)], axis=1).astype(np.float32)
+    flat = m.Mesh(flat_v, np.tile([[0, 1, 0]], (200, 1)), rng.integers(0, 200, 3 * 150).astype(np.int32), "flat")
+    # a single point (all sizes 0 -> 0/0 NaN in the split count)
+    point = m.Mesh(np.zeros((3, 3), np.float32), np.tile([[0, 1, 0]], (3, 1)), np.tile([0, 1, 2], 12).astype(np.int32), "point")
+    one = m.Mesh(v[:3], np.tile([[0, 1, 0]], (3, 1)), np.array([0, 1, 2], np.int32), "one")
+    return [m.quad(), m.cube(), m.rounded_cube(6), m.icosphere(3), m.icosphere(3, 1.0, 4), soup, same, flat, point, one]
+
+
+@pytest.mark.parametrize("quality", [0, 1, 2])
+def test_product_builder_equals_oracle_builder(pkg, api, orc, quality):
+    for mesh in mesh_cases(pkg):
+        (n1, t1, s1), (n2, t2, s2) = both(api, orc, mesh, quality)
+        assert n1.tobytes() == n2.tobytes(), (mesh.name, quality)
+        assert t1.tobytes() == t2.tobytes(), (mesh.name, quality)
+        s1.pop("timeMs"), s2.pop("timeMs")
+        assert s1 == s2, (mesh.name, quality)
+
+
+def test_empty_mesh_builds_a_single_empty_leaf(pkg, api, orc):
+    mesh = pkg.meshes.Mesh(np.zeros((3, 3), np.float32), np.zeros((3, 3), np.float32), np.zeros(0, np.int32), "empty")
+    (n1, t1, _), (n2, t2, _) = both(api, orc, mesh, 1)
+    assert len(n1) == len(n2) == 1 and len(t1) == len(t2) == 0
+    assert n1[0]["triangleCount"] == 0 and n1.tobytes() == n2.tobytes()
+
+
+def test_tree_structure_invariants(pkg, api):
+    """What the kernel relies on: children adjacent (BVH:161-162), inner root keeps
+    triangleCount -1 (BVH:61), inner non-root 0, leaves partition the triangle range,
+    depth <= 32, child bounds inside parent bounds."""
+    mesh = pkg.meshes.icosphere(4, 1.0, 9)
+    nodes, tris, stats = api.build_bvh_arrays(mesh.vertices, mesh.normals, mesh.triangles, 1)
+    assert nodes[0]["triangleCount"] == -1 and nodes[0]["startIndex"] == 1
+    covered = np.zeros(len(tris), dtype=int)
+    stack = [(0, 0)]
+    maxdepth = 0
+    while stack:
+        i, d = stack.pop()
+        n = nodes[i]
+        maxdepth = max(maxdepth, d)
+        if n["triangleCount"] > 0:
+            covered[n["startIndex"]: n["startIndex"] + n["triangleCount"]] += 1
+            t = tris[n["startIndex"]: n["startIndex"] + n["triangleCount"]]
+            pts = np.concatenate([t["posA"], t["posB"], t["posC"]])
+            assert np.all(pts.min(0) == n["boundsMin"]) and np.all(pts.max(0) == n["boundsMax"])
+        else:
+            assert i == 0 or n["triangleCount"] == 0
+            a = n["startIndex"]
+            assert a % 2 == 1  # pairs sit at (odd, even) indices: node 0 is the root
+            for c in (a, a + 1):
+                assert np.all(nodes[c]["boundsMin"] >= n["boundsMin"]) and np.all(nodes[c]["boundsMax"] <= n["boundsMax"])
+                stack.append((c, d + 1))
+    assert np.all(covered == 1)
+    assert maxdepth == stats["leafDepthMax"] <= 32
+    assert stats["triangleCount"] == len(tris) == mesh.triangle_count
+    assert stats["totalNodeCount"] == len(nodes)
+
+
+def _scene_tracer(pkg, orc, cfg, **kw):
+    tr = orc.create_tracer(1)
+    sc = pkg.scenes.get(cfg, **kw)
+    mgr = sc.make_manager(tr, orc, 32, 18)
+    mgr.OnEnable(renderSeed=1)
+    return tr, sc
+
+
+@pytest.mark.parametrize("cfg,kw", [(2, {}), (3, {}), (4, {"subdivisions": 3})])
+def test_bvh_traversal_equals_bruteforce(pkg, orc, cfg, kw):
+    tr, sc = _scene_tracer(pkg, orc, cfg, **kw)
+    rng = np.random.default_rng(cfg)
+    n = 3000
+    o = rng.uniform(-2.5, 2.5, (n, 3)) + np.array([0, 2, 0])
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # axis-parallel rays exercise invDir = inf
+    d[:60] = np.eye(3)[rng.integers(0, 3, 60)] * rng.choice([-1, 1], (60, 1))
+    hits = 0
+    for i in range(n):
+        a = (C.c_float * 10)()
+        b = (C.c_float * 2)()
+        oo = (C.c_float * 3)(*o[i])
+        dd = (C.c_float * 3)(*d[i])
+        orc.ray_collision(tr.h, oo, dd, a)
+        orc.ray_collision_bruteforce(tr.h, oo, dd, b)
+        assert a[0] == b[0]
+        if a[0]:
+            hits += 1
+            assert a[2] == b[1], (i, a[2], b[1])
+    assert hits > n // 4
+    tr.close()

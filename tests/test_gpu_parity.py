@@ -1,0 +1,313 @@
+"""GPU parity tests: libraytrace_hip.so (through the C ABI) against the CPU oracle.
+
+Bar: BIT-EXACT on the raw accumulation sum buffer (stronger than the 1e-4 relative
+per-channel tolerance BASELINE.json's north_star allows) and identical exact work
+counters.  At BASELINE sizes, where the oracle would take minutes, parity is checked
+through size-independent properties: determinism, partition invariance (row-tiled
+shards == whole image), batch == repeated single frames, alpha == frame count,
+frame additivity, and a strip-sampled oracle comparison.
+"""
+import numpy as np
+import pytest
+
+from conftest import render
+
+pytestmark = pytest.mark.gpu
+KEYS = ["segments", "innerSteps", "leafSteps", "triTests", "sphereTests", "modelVisits", "pixelFrames"]
+
+
+def bits_equal(a, b):
+    return a.shape == b.shape and bool(np.all(a.view(np.uint32) == b.view(np.uint32)))
+
+
+def rel_err(a, b):
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    return float(np.max(d / np.maximum(np.abs(b.astype(np.float64)), 1e-30)))
+
+
+def pair(pkg, api, orc, cfg, w, h, frames, seed=1, scene_kw=None, tweak=None, stats=True):
+    g = api.create_tracer(0)
+    if stats:
+        g.enable_stats(True)
+    c = orc.create_tracer(8)
+    a, _ = render(pkg, api, g, cfg, w, h, frames, seed, scene_kw, tweak)
+    b, _ = render(pkg, orc, c, cfg, w, h, frames, seed, scene_kw, tweak)
+    ca, cb = g.counters(), c.counters()
+    g.close(), c.close()
+    return a, b, ca, cb
+
+
+@pytest.mark.parametrize("cfg,w,h,frames,kw", [
+    (1, 256, 256, 1, None),          # BASELINE configs[0] exactly (CPU reference case)
+    (1, 100, 60, 3, None),
+    (2, 240, 135, 2, None),
+    (3, 160, 90, 2, None),
+    (3, 61, 35, 2, None),            # ragged tiles
+    (4, 128, 72, 1, {"subdivisions": 4}),   # depth of field + glass blob
+    (5, 96, 54, 1, {"subdivisions": 3, "n_meshes": 12}),  # many models, 12 bounces
+])
+def test_bit_exact_against_oracle(pkg, api, orc, cfg, w, h, frames, kw):
+    a, b, ca, cb = pair(pkg, api, orc, cfg, w, h, frames, scene_kw=kw)
+    assert rel_err(a, b) <= 1e-4          # the north_star tolerance ...
+    assert bits_equal(a, b)               # ... and in fact every bit
+    assert [ca[k] for k in KEYS] == [cb[k] for k in KEYS]
+
+
+def test_config4_full_mesh_bit_exact(pkg, api, orc):
+    """The real 81,920-triangle mesh (BVH depth ~20), small image."""
+    a, b, ca, cb = pair(pkg, api, orc, 4, 96, 54, 1)
+    assert bits_equal(a, b)
+    assert [ca[k] for k in KEYS] == [cb[k] for k in KEYS]
+
+
+@pytest.mark.parametrize("seed", [0, 12345, 2147483647, -5])
+def test_seeds_and_frame_offsets(pkg, api, orc, seed):
+    a, b, _, _ = pair(pkg, api, orc, 2, 64, 36, 2, seed=seed)
+    assert bits_equal(a, b)
+
+
+def test_parameter_edges(pkg, api, orc):
+    def no_bounce(m):
+        m.maxBounceCount = 0          # one segment per path (RC:485 inclusive loop)
+
+    def one_spp_nosky_noaccum(m):
+        m.numRaysPerPixel = 1
+        m.useSky = False
+
+    def deep(m):
+        m.maxBounceCount = 32         # inspector maximum (RCM:15)
+        m.numRaysPerPixel = 2
+
+    def dof(m):
+        m.defocusStrength = 150.0
+        m.focusDistance = 7.0
+        m.divergeStrength = 0.0
+    for tweak in (no_bounce, one_spp_nosky_noaccum, deep, dof):
+        a, b, ca, cb = pair(pkg, api, orc, 3 if tweak is deep else 2, 64, 36, 2, tweak=tweak)
+        assert bits_equal(a, b), tweak.__name__
+        assert ca["segments"] == cb["segments"]
+
+
+def test_bvh_qualities_and_oversized_leaf(pkg, api, orc):
+    # Quality.Disabled puts all 1,728 triangles of the rounded cube in ONE leaf (> 127: indirect leaf code)
+    for q in (0, 2):
+        def tweak(m, q=q):
+            m.bvhQuality = q
+        a, b, ca, cb = pair(pkg, api, orc, 3, 48, 27, 1, tweak=tweak)
+        assert bits_equal(a, b)
+        assert [ca[k] for k in KEYS] == [cb[k] for k in KEYS]
+
+
+def test_frame_render_and_no_accumulate(pkg, api, orc):
+    """FrameRender holds the last frame (RCC:18); with accumulate off the sum buffer is untouched."""
+    outs = []
+    for lib, tr in ((api, api.create_tracer(0)), (orc, orc.create_tracer(4))):
+        sc = pkg.scenes.get(2)
+        mgr = sc.make_manager(tr, lib, 64, 36)
+        mgr.OnEnable(renderSeed=9)
+        mgr.RenderFrames(2)
+        acc2 = tr.read_accumulated()
+        mgr.accumulate = False
+        mgr.RenderFrame()
+        outs.append((tr.read_frame(), tr.read_accumulated(), acc2, tr.frame()))
+        tr.close()
+    (f1, a1, p1, n1), (f2, a2, p2, n2) = outs
+    assert bits_equal(f1, f2) and bits_equal(a1, a2) and bits_equal(a1, p1)
+    assert n1 == n2 == 3 and np.all(f1[..., 3] == 1)
+
+
+def test_empty_scene_and_sphere_only_and_models_only(pkg, api, orc):
+    for variant in ("empty", "spheres", "models"):
+        outs = []
+        for lib, tr in ((api, api.create_tracer(0)), (orc, orc.create_tracer(4))):
+            sc = pkg.scenes.get(2)
+            if variant == "empty":
+                sc.models, sc.spheres = [], []
+            elif variant == "spheres":
+                sc.models = []
+            else:
+                sc.spheres = []
+            mgr = sc.make_manager(tr, lib, 48, 27)
+            mgr.OnEnable(renderSeed=1)
+            mgr.RenderFrames(1)
+            outs.append(tr.read_accumulated())
+            tr.close()
+        assert bits_equal(*outs), variant
+
+
+def test_update_models_and_spheres_between_frames(pkg, api, orc):
+    outs = []
+    for lib, tr in ((api, api.create_tracer(0)), (orc, orc.create_tracer(4))):
+        sc = pkg.scenes.get(3)
+        mgr = sc.make_manager(tr, lib, 64, 36)
+        mgr.OnEnable(renderSeed=2)
+        mgr.RenderFrame()
+        # move the glass cube, recolour a wall — RCM:192-204 refreshes matrices + materials every frame
+        mgr.models[7].transform = pkg.Transform((-0.6, 0.9, 0.2), (20, 60, 0), 1.0)
+        mgr.models[2].material.diffuseCol = (0.1, 0.2, 0.9, 1)
+        mgr.RenderFrame()
+        outs.append(tr.read_accumulated())
+        tr.close()
+    assert bits_equal(*outs)
+
+
+def test_debug_intersect_matches_oracle_ray_collision(pkg, api, orc):
+    import ctypes as C
+    g, c = api.create_tracer(0), orc.create_tracer(1)
+    for lib, tr in ((api, g), (orc, c)):
+        mgr = pkg.scenes.get(4, subdivisions=4).make_manager(tr, lib, 32, 18)
+        mgr.OnEnable(renderSeed=1)
+    rng = np.random.default_rng(11)
+    n = 4096
+    o = (rng.uniform(-2, 2, (n, 3)) + [0, 2, 0]).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[:64] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 64)]     # axis-parallel: invDir = inf
+    got = g.debug_intersect(o, d)
+    want = np.zeros_like(got)
+    for i in range(n):
+        out = (C.c_float * 10)()
+        orc.ray_collision(c.h, (C.c_float * 3)(*o[i]), (C.c_float * 3)(*d[i]), out)
+        want[i] = list(out)
+    hit = want[:, 0] == 1
+    assert hit.sum() > n // 2
+    assert np.array_equal(got[:, 0], want[:, 0])
+    assert bits_equal(got[hit], want[hit])
+    assert np.all(np.isinf(got[~hit, 2]))
+    g.close(), c.close()
+
+
+# ------------------------------------------------------------------ BASELINE sizes: properties
+def full_size(pkg, api, cfg=2, frames=2, partition=None, seed=1, batch=True):
+    tr = api.create_tracer(0)
+    if partition:
+        tr.set_partition(8, *partition)
+    sc = pkg.scenes.get(cfg)
+    mgr = sc.make_manager(tr, api)
+    mgr.OnEnable(renderSeed=seed)
+    if batch:
+        mgr.RenderFrames(frames)
+    else:
+        for _ in range(frames):
+            mgr.RenderFrame()
+    acc = tr.read_accumulated()
+    rows = tr.local_to_global_rows() if partition else None
+    c = tr.counters()
+    tr.close()
+    return acc, rows, c
+
+
+def test_full_size_determinism_alpha_and_batching(pkg, api):
+    a, _, ca = full_size(pkg, api, 2, 2)
+    b, _, cb = full_size(pkg, api, 2, 2, batch=False)
+    assert a.shape == (1080, 1920, 4)
+    assert bits_equal(a, b) and ca["segments"] == cb["segments"]
+    assert np.all(a[..., 3] == 2.0)
+    assert np.all(np.isfinite(a)) and np.all(a[..., :3] >= 0)
+    # upper bound of segments: W*H*spp*(maxBounce+1) per frame; lower bound: one per path
+    assert 1920 * 1080 * 8 * 2 <= ca["segments"] <= 1920 * 1080 * 8 * 9 * 2
+
+
+def test_full_size_row_tiled_shards_equal_whole_image(pkg, api):
+    """Virtual shards on one device: 3 partitions rendered separately == the single render,
+    bitwise (the multi-GPU path renders with global pixel ids)."""
+    whole, _, cw = full_size(pkg, api, 2, 1)
+    out = np.zeros_like(whole)
+    seg = 0
+    for r in range(3):
+        acc, rows, c = full_size(pkg, api, 2, 1, partition=(r, 3))
+        assert np.array_equal(rows, pkg.dist.global_rows_of(r, 3, 1080))
+        out[rows] = acc
+        seg += c["segments"]
+    assert bits_equal(out, whole) and seg == cw["segments"]
+
+
+def test_full_size_frame_additivity(pkg, api):
+    """Accumulating frames 1..2 == frame 1 + frame 2 rendered independently and added in fp32
+    in frame order (RCC:22) — checks the Frame-seeded RNG streams are independent of history."""
+    both, _, _ = full_size(pkg, api, 2, 2)
+    tr = api.create_tracer(0)
+    mgr = pkg.scenes.get(2).make_manager(tr, api)
+    mgr.OnEnable(renderSeed=1)
+    mgr.RenderFrame()
+    f1 = tr.read_frame()
+    mgr.RenderFrame()
+    f2 = tr.read_frame()
+    tr.close()
+    assert bits_equal((f1 + f2), both)
+
+
+def test_full_size_strip_sample_against_oracle(pkg, api, orc):
+    """Config 2 at 1920x1080: three 8-row strips of frame 1 against the oracle, bit for bit."""
+    tr = api.create_tracer(0)
+    mgr = pkg.scenes.get(2).make_manager(tr, api)
+    mgr.OnEnable(renderSeed=1)
+    mgr.RenderFrame()
+    gpu = tr.read_accumulated()
+    tr.close()
+    c = orc.create_tracer(8)
+    m2 = pkg.scenes.get(2).make_manager(c, orc)
+    m2.OnEnable(renderSeed=1)
+    for s in (3, 60, 131):
+        m2.numAccumulatedFrames = 1
+        m2.SetShaderParams()
+        orc.set_row_window(c.h, s * 8, s * 8 + 8)
+        c.render_frame()
+    cpu = c.read_accumulated()
+    c.close()
+    for s in (3, 60, 131):
+        assert bits_equal(gpu[s * 8: s * 8 + 8], cpu[s * 8: s * 8 + 8]), s
+
+
+def test_config3_full_size_strip_sample(pkg, api, orc):
+    tr = api.create_tracer(0)
+    mgr = pkg.scenes.get(3).make_manager(tr, api)
+    mgr.OnEnable(renderSeed=1)
+    mgr.RenderFrame()
+    gpu = tr.read_accumulated()
+    tr.close()
+    c = orc.create_tracer(8)
+    m2 = pkg.scenes.get(3).make_manager(c, orc)
+    m2.OnEnable(renderSeed=1)
+    for s in (20, 100):
+        m2.numAccumulatedFrames = 1
+        m2.SetShaderParams()
+        orc.set_row_window(c.h, s * 8, s * 8 + 8)
+        c.render_frame()
+    cpu = c.read_accumulated()
+    c.close()
+    for s in (20, 100):
+        assert bits_equal(gpu[s * 8: s * 8 + 8], cpu[s * 8: s * 8 + 8]), s
+
+
+# ------------------------------------------------------------------ error behaviour of the ABI
+def test_abi_errors(pkg, api):
+    a = pkg.abi
+    tr = api.create_tracer(0)
+    with pytest.raises(a.RtError) as e:
+        tr.render_frame()
+    assert e.value.status == a.RT_ERR_STATE
+    tr.resize(32, 32)
+    p = a.RtParams()
+    p.abi_version, p.struct_size = 99, 4
+    import ctypes as C
+    assert api.set_params(tr.h, C.byref(p)) == a.RT_ERR_ABI_MISMATCH
+    assert b"abi_version" in api.last_error(tr.h)
+    # inconsistent scene: child index out of range / empty mesh / bad offsets -> RT_ERR_SCENE, no crash
+    m = np.zeros(1, a.model_dtype)
+    nodes = np.zeros(1, a.node_dtype)
+    nodes[0]["triangleCount"] = -1
+    nodes[0]["startIndex"] = 5
+    with pytest.raises(a.RtError) as e:
+        tr.upload_scene(m, np.zeros(0, a.triangle_dtype), nodes)
+    assert e.value.status == a.RT_ERR_SCENE
+    nodes[0]["triangleCount"] = 3
+    nodes[0]["startIndex"] = 0
+    with pytest.raises(a.RtError) as e:
+        tr.upload_scene(m, np.zeros(2, a.triangle_dtype), nodes)   # leaf wants 3 triangles, buffer has 2
+    assert e.value.status == a.RT_ERR_SCENE
+    with pytest.raises(a.RtError):
+        tr.set_partition(7, 0, 1)    # strips must be multiples of 8
+    out = np.zeros((4, 4, 4), np.float32)
+    assert api.read_accumulated(tr.h, out.ctypes.data, out.nbytes) == a.RT_ERR_INVALID_ARG
+    tr.close()
