@@ -32,36 +32,28 @@ import __graft_entry__ as graft  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(pkg, scene_id, width, height, budget_s=20.0):
-    """The CPU oracle (a port of the reference's loop, 1 thread) timed on a bounded
-    sample of the same workload: every k-th 8-row strip of frame 1."""
+def cpu_baseline(pkg, scene_id, width, height, min_s=10.0, max_frames=4):
+    """The CPU oracle (a port of the reference's loop, ONE thread) timed on a bounded
+    sample of the same workload: whole frames 1, 2, ... of the same scene at the same
+    resolution until at least `min_s` seconds of CPU work are done."""
     orc = graft.load_oracle()
     tr = orc.create_tracer(threads=1)
     sc = pkg.scenes.get(scene_id)
     mgr = sc.make_manager(tr, orc, width, height)
     mgr.OnEnable(renderSeed=1)
-    n_strips = (height + 7) // 8
-    want = 10
-    strips = [int(round(i * (n_strips - 1) / (want - 1))) for i in range(want)]
     tr.reset_counters()
     t0 = time.perf_counter()
-    used = 0
-    for s in strips:
-        mgr.numAccumulatedFrames = 1
-        mgr.SetShaderParams()
-        orc.set_row_window(tr.h, s * 8, min(s * 8 + 8, height))
-        tr.render_frame()
-        used += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
+    frames = 0
+    while frames < max_frames and (frames == 0 or time.perf_counter() - t0 < min_s):
+        mgr.RenderFrame()
+        frames += 1
     dt = time.perf_counter() - t0
     c = tr.counters()
     tr.close()
     return {
         "value": c["segments"] / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-        "sample": f"oracle/rt_oracle.cpp, 1 thread: frame 1 of the same scene at {width}x{height}, "
-                  f"{used} of {n_strips} 8-row strips spread over the image "
-                  f"({c['segments']} segments in {dt:.1f} s)",
+        "sample": f"oracle/rt_oracle.cpp (g++ -O2, strict fp32), 1 thread: frames 1..{frames} of the same scene at "
+                  f"{width}x{height} ({c['segments']} segments in {dt:.1f} s)",
         "nproc": os.cpu_count(),
     }
 

@@ -195,6 +195,24 @@ RT_HD float rt_cos(float x)
     return ((n + 1) & 2) ? -c : c;
 }
 
+/* cos(x) and sin(x) of the same argument sharing one range reduction; bit-identical
+ * to calling rt_cos(x) and rt_sin(x) separately (same operations on the same r). */
+RT_HD void rt_sincos(float x, float* s_out, float* c_out)
+{
+    if (!(rt_abs(x) < 3.0e4f)) {
+        *s_out = rt_sin(x);
+        *c_out = rt_cos(x);
+        return;
+    }
+    float r;
+    int n = rt_reduce_pio2(x, &r);
+    float sk = rt_sin_kernel(r), ck = rt_cos_kernel(r);
+    float s = (n & 1) ? ck : sk;
+    float c = (n & 1) ? sk : ck;
+    *s_out = (n & 2) ? -s : s;
+    *c_out = ((n + 1) & 2) ? -c : c;
+}
+
 /* ---------------------------------------------------------------- vectors */
 struct rt_f3 { float x, y, z; };
 struct rt_f2 { float x, y; };
@@ -214,9 +232,13 @@ RT_HD rt_f3 rt_cross(rt_f3 a, rt_f3 b)
 {
     return rt_v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-/* HLSL normalize(): defined here as v / sqrt(dot(v,v)) (correctly rounded sqrt
- * and divide; a zero vector gives NaNs exactly like 0 * rsqrt(0)). */
-RT_HD rt_f3 rt_normalize(rt_f3 v) { return v / rt_sqrt(rt_dot(v, v)); }
+/* HLSL rsqrt(): the hardware instruction is an approximation; the strict
+ * definition here is 1/sqrt(x) with both operations correctly rounded. */
+RT_HD float rt_rsqrt(float x) { return 1.0f / rt_sqrt(x); }
+/* HLSL normalize(): DXC lowers it to v * rsqrt(dot(v,v)) — followed here with
+ * the strict rsqrt above (one sqrt, one divide, three multiplies).  A zero
+ * vector gives NaNs (0 * inf), like the shader. */
+RT_HD rt_f3 rt_normalize(rt_f3 v) { return v * rt_rsqrt(rt_dot(v, v)); }
 RT_HD rt_f3 rt_lerp3(rt_f3 a, rt_f3 b, float t)
 {
     return rt_v3(rt_lerp(a.x, b.x, t), rt_lerp(a.y, b.y, t), rt_lerp(a.z, b.z, t));

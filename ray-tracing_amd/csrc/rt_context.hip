@@ -435,7 +435,7 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
     std::vector<DMaterial> mats((size_t)n_spheres + n_models);
     for (int i = 0; i < n_spheres; i++) {
         memcpy(&sph[4 * i], spheres[i].centre, 12);
-        sph[4 * i + 3] = spheres[i].radius;
+        sph[4 * i + 3] = spheres[i].radius * spheres[i].radius; /* RC:299 */
         pack_material(spheres[i].material, mats[i]);
     }
     std::vector<DModel> dmodels(n_models);
@@ -495,7 +495,7 @@ int rt_update_spheres(RtContext* ctx, const RtSphere* spheres, int n_spheres)
     std::vector<DMaterial> mats(n_spheres);
     for (int i = 0; i < n_spheres; i++) {
         memcpy(&sph[4 * i], spheres[i].centre, 12);
-        sph[4 * i + 3] = spheres[i].radius;
+        sph[4 * i + 3] = spheres[i].radius * spheres[i].radius;
         pack_material(spheres[i].material, mats[i]);
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -70,7 +70,7 @@ struct DMaterial {
 
 struct KArgs {
     /* scene */
-    const float* spheres;        /* nSpheres x (cx, cy, cz, r) */
+    const float* spheres;        /* nSpheres x (cx, cy, cz, r*r) */
     const DMaterial* materials;  /* [0,nSpheres) spheres, then models */
     const DModel* models;
     const DPair* pairs;

@@ -88,7 +88,8 @@ __device__ __forceinline__ rt_f3 rand_direction(uint32_t* state)
 __device__ __forceinline__ rt_f2 rand_circle(uint32_t* state)
 {
     float angle = rt_random_value(state) * 2 * 3.1415f;
-    float c = rt_cos(angle), s = rt_sin(angle);
+    float c, s;
+    rt_sincos(angle, &s, &c); /* == rt_cos(angle), rt_sin(angle): one shared range reduction */
     float r = rt_sqrt(rt_random_value(state));
     rt_f2 o = {c * r, s * r};
     return o;
@@ -244,17 +245,35 @@ __device__ __forceinline__ void intersect_scene(const KArgs& a, rt_f3 rpos, rt_f
     h.u = h.v = h.det = 0.0f;
     h.backface = false;
 
-    /* RaySphere — RC:289-332 */
+    /* RaySphere — RC:289-332, in two phases so the expensive part (sqrt + two divides)
+     * runs only for (ray, sphere) pairs whose discriminant is non-negative:
+     *   phase 1, wave-uniform loop, sphere data in SGPRs: discriminant only -> per-lane bitmask;
+     *   phase 2, per lane: walk the set bits in increasing sphere order (strict '<' keeps
+     *   the first of equal hits, like the reference's in-order loop) and redo the same
+     *   fp32 operations for that sphere, then the roots.
+     * 4th float of a sphere record is radius*radius, computed on upload with the same fp32 multiply. */
     const RT_CAS float* sph = (const RT_CAS float*)a.spheres;
-    for (int s = 0; s < a.nSpheres; s++) {
-        rt_f3 centre = rt_v3(sph[4 * s + 0], sph[4 * s + 1], sph[4 * s + 2]);
-        float radius = sph[4 * s + 3];
-        rt_f3 off = rpos - centre;
-        float qa = rt_dot(rdir, rdir);
-        float qb = 2 * rt_dot(off, rdir);
-        float qc = rt_dot(off, off) - radius * radius;
-        float disc = qb * qb - 4 * qa * qc;
-        if (disc >= 0) {
+    const float qa = rt_dot(rdir, rdir);
+    for (int base = 0; base < a.nSpheres; base += 32) {
+        const int n = (a.nSpheres - base) < 32 ? (a.nSpheres - base) : 32;
+        uint32_t cand = 0;
+        for (int k = 0; k < n; k++) {
+            const int s = base + k;
+            rt_f3 off = rpos - rt_v3(sph[4 * s + 0], sph[4 * s + 1], sph[4 * s + 2]);
+            float qb = 2 * rt_dot(off, rdir);
+            float qc = rt_dot(off, off) - sph[4 * s + 3];
+            float disc = qb * qb - 4 * qa * qc;
+            cand |= (disc >= 0 ? 1u : 0u) << k;
+        }
+        while (cand) {
+            const int k = __builtin_ctz(cand);
+            cand &= cand - 1;
+            const int s = base + k;
+            const float4 sp = *reinterpret_cast<const float4*>(a.spheres + 4 * s);
+            rt_f3 off = rpos - rt_v3(sp.x, sp.y, sp.z);
+            float qb = 2 * rt_dot(off, rdir);
+            float qc = rt_dot(off, off) - sp.w;
+            float disc = qb * qb - 4 * qa * qc;
             float sq = rt_sqrt(disc);
             float dstNear = rt_max(0.0f, (-qb - sq) / (2 * qa));
             float dstFar = (-qb + sq) / (2 * qa);
@@ -281,7 +300,9 @@ __device__ __forceinline__ void intersect_scene(const KArgs& a, rt_f3 rpos, rt_f
         rt_f3 ldir = rt_v3(M.w2l[0] * rdir.x + M.w2l[1] * rdir.y + M.w2l[2] * rdir.z + M.w2l[3] * 0.0f,
                            M.w2l[4] * rdir.x + M.w2l[5] * rdir.y + M.w2l[6] * rdir.z + M.w2l[7] * 0.0f,
                            M.w2l[8] * rdir.x + M.w2l[9] * rdir.y + M.w2l[10] * rdir.z + M.w2l[11] * 0.0f);
-        rt_f3 linv = rt_v3(1 / ldir.x, 1 / ldir.y, 1 / ldir.z);
+        /* invDir (RC:353) is only read by box tests: a mesh whose root is a leaf has none */
+        rt_f3 linv = rt_v3s(0.0f);
+        if (!(M.rootCode & RT_CODE_LEAF)) linv = rt_v3(1 / ldir.x, 1 / ldir.y, 1 / ldir.z);
         float best = h.dst;
         int bestTri = -1;
         float bu = 0, bv = 0, bdet = 0;
@@ -431,8 +452,17 @@ __global__ void __launch_bounds__(RT_WAVE) rt_trace_kernel(const KArgs a)
                 resolve_hit(a, rpos, rdir, h, hpos, normal);
                 const DMaterial mat = a.materials[h.obj];
 
-                if (mat.flag == RT_MATERIAL_GLASS) { /* RC:499-518 */
-                    if (h.backface) {
+                /* The glass (RC:499-518) and opaque (RC:519-533) branches both draw
+                 * diffuseDir = normalize(normal + RandomDirection) — the costliest piece
+                 * (3 log, 3 cos, 4 sqrt).  It is hoisted so that all hit lanes execute it
+                 * together; each lane still consumes its random numbers in its branch's
+                 * order: opaque = [isSpecular, direction x6], glass = [direction x6, choice]. */
+                const bool isGlass = mat.flag == RT_MATERIAL_GLASS;
+                float uSpec = 0.0f;
+                if (!isGlass) uSpec = rt_random_value(&rng); /* RC:521 */
+                const rt_f3 diffuseDir = rt_normalize(normal + rand_direction(&rng)); /* RC:509 / RC:525 */
+                if (isGlass) {
+                    if (h.backface) { /* RC:502 */
                         rt_f3 e = ((-h.dst) * rt_v3(mat.absorption[0], mat.absorption[1], mat.absorption[2])) * mat.absorptionStrength;
                         transmittance = transmittance * rt_v3(rt_exp(e.x), rt_exp(e.y), rt_exp(e.z));
                     }
@@ -441,16 +471,14 @@ __global__ void __launch_bounds__(RT_WAVE) rt_trace_kernel(const KArgs a)
                     rt_f3 reflectDir = rdir - (2 * rt_dot(rdir, normal)) * normal; /* RC:419-422 */
                     rt_f3 refractDir = refract_dir(rdir, normal, iorCurrent, iorNext);
                     float reflectWeight = reflectance(rdir, normal, iorCurrent, iorNext);
-                    rt_f3 diffuseDir = rt_normalize(normal + rand_direction(&rng));
                     reflectDir = rt_normalize(rt_lerp3(diffuseDir, reflectDir, mat.specularProbability));
                     refractDir = rt_normalize(rt_lerp3(-diffuseDir, refractDir, mat.smoothness));
-                    bool followReflection = rt_random_value(&rng) <= reflectWeight;
+                    bool followReflection = rt_random_value(&rng) <= reflectWeight; /* RC:515 */
                     rdir = followReflection ? reflectDir : refractDir;
                     rpos = hpos + (0.001f * normal) * rt_sign(rt_dot(normal, rdir));
-                } else { /* RC:519-533 */
-                    bool isSpecular = mat.specularProbability >= rt_random_value(&rng);
+                } else {
+                    bool isSpecular = mat.specularProbability >= uSpec;
                     rpos = hpos + (normal * 0.001f);
-                    rt_f3 diffuseDir = rt_normalize(normal + rand_direction(&rng));
                     rt_f3 specularDir = rt_reflect(rdir, normal);
                     rdir = rt_normalize(rt_lerp3(diffuseDir, specularDir, mat.smoothness * (isSpecular ? 1.0f : 0.0f)));
                     rt_f3 emitted = rt_v3(mat.emissionCol[0], mat.emissionCol[1], mat.emissionCol[2]) * mat.emissionStrength;

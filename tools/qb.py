@@ -1,0 +1,38 @@
+"""Quick GPU benchmark of several configs: Mrays/s + ms/frame (device events), golden check first.
+usage: python tools/qb.py [configs, default 2,3,4] [frames]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import __graft_entry__ as g
+
+pkg = g.load_package(); api = pkg.load_library()
+cfgs = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "2,3,4").split(",")]
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+
+# correctness gate: golden fixtures through the HIP path
+import importlib.util
+spec = importlib.util.spec_from_file_location("mg", os.path.join(g.ROOT, "tests", "golden", "make_golden.py"))
+mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+bad = []
+for case in sorted(mg.CASES):
+    z = np.load(os.path.join(g.ROOT, "tests", "golden", case + ".npz"))
+    tr = api.create_tracer(0); tr.enable_stats(True)
+    acc, cnt = mg.render_case(pkg, api, tr, case); tr.close()
+    if not (np.array_equal(acc.view(np.uint32), z["accumulated"].view(np.uint32)) and cnt.tolist() == z["counters"].tolist()):
+        bad.append(case)
+print("golden:", "ALL BIT-EXACT" if not bad else "MISMATCH " + str(bad))
+
+for cfg in cfgs:
+    t0 = time.time()
+    tr = api.create_tracer(0)
+    sc = pkg.scenes.get(cfg); mgr = sc.make_manager(tr, api); mgr.OnEnable(renderSeed=1)
+    tb = time.time() - t0
+    mgr.RenderFrames(1); tr.synchronize()
+    best = None
+    for rep in range(3):
+        tr.reset_counters(); tr.timer_begin(); tr.render_frames(frames); tr.timer_end()
+        c = tr.counters()
+        ms = c["gpuMs"] / frames
+        if best is None or ms < best[0]: best = (ms, c["segments"] / c["gpuMs"] / 1e3)
+    print(f"config {cfg}: {best[0]:8.3f} ms/frame  {best[1]:9.1f} Mrays/s   (segments/frame {c['segments']/frames:.3e}, setup {tb:.1f}s)")
+    tr.close()
