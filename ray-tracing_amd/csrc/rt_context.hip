@@ -47,6 +47,7 @@ struct RtContext {
     DTriN* dNorms = nullptr;
     uint32_t* dBigLeaves = nullptr;
     int nSpheres = 0, nModels = 0, nTris = 0, nPairs = 0;
+    int stackEntries = 1; /* deepest BVH of the scene = most entries a lane can push */
     bool haveScene = false;
     /* scene (host mirrors needed by rt_update_models) */
     std::vector<RtModel> hModels;
@@ -398,6 +399,7 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
     sb.nTris = n_triangles;
     sb.pairOfFirstChild.assign((size_t)n_nodes + 1, -1);
     std::vector<uint32_t> rootCodes(n_models);
+    int maxHeight = 1;
     for (int i = 0; i < n_models; i++) {
         const RtModel& m = models[i];
         if (m.nodeOffset < 0 || m.nodeOffset >= n_nodes || m.triOffset < 0 || m.triOffset > n_triangles)
@@ -409,6 +411,7 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
         if (!sb.convert(m.nodeOffset, m.triOffset, m.nodeOffset, &rootCodes[i], &height))
             return fail(ctx, RT_ERR_SCENE, "model %d: %s", i, sb.error.c_str());
         if (height > RT_MAX_BVH_DEPTH) return fail(ctx, RT_ERR_SCENE, "model %d: BVH depth %d > %d", i, height, RT_MAX_BVH_DEPTH);
+        if (height > maxHeight) maxHeight = height;
     }
 
     /* ---- triangles: RC:190-192 are ray independent, pre-difference them (same fp32 ops) */
@@ -457,6 +460,7 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
     ctx->nModels = n_models;
     ctx->nTris = n_triangles;
     ctx->nPairs = (int)sb.pairs.size();
+    ctx->stackEntries = maxHeight;
     ctx->hModels.assign(models, models + n_models);
     ctx->hRootCodes = rootCodes;
     ctx->haveScene = true;
@@ -582,10 +586,11 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
     fill_args(ctx, frame0, nFrames, a);
     int tiles = a.tilesX * a.tilesY;
     if (tiles == 0) return RT_OK;
+    const size_t stackBytes = (size_t)ctx->stackEntries * RT_WAVE * sizeof(uint32_t);
     if (ctx->stats)
-        hipLaunchKernelGGL(rtk::rt_trace_kernel<true>, dim3(tiles), dim3(RT_WAVE), 0, ctx->stream, a);
+        hipLaunchKernelGGL(rtk::rt_trace_kernel<true>, dim3(tiles), dim3(RT_WAVE), stackBytes, ctx->stream, a);
     else
-        hipLaunchKernelGGL(rtk::rt_trace_kernel<false>, dim3(tiles), dim3(RT_WAVE), 0, ctx->stream, a);
+        hipLaunchKernelGGL(rtk::rt_trace_kernel<false>, dim3(tiles), dim3(RT_WAVE), stackBytes, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
     ctx->pixelFrames += (uint64_t)ctx->localRows * ctx->W * nFrames;
     return RT_OK;

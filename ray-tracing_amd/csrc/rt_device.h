@@ -35,6 +35,7 @@
  * triangle (relative to the model's triOffset); count field 0 = indirect, [23:0]
  * indexes bigLeaves {start,count}.  inner: [30:0] = absolute DPair index. */
 #define RT_CODE_LEAF 0x80000000u
+#define RT_CODE_NEXT_MODEL 0x7fffffffu /* traversal state: this model is finished */
 #define RT_CODE_MAX_INLINE_COUNT 127
 #define RT_CODE_MAX_INLINE_START 0x00ffffffu
 
@@ -55,7 +56,7 @@ struct DTriN {
 struct DModel {
     float w2l[12]; /* row r: m[r], m[4+r], m[8+r], m[12+r] of worldToLocal */
     float l2w[12];
-    uint32_t rootCode;
+    uint32_t rootCode;    /* 16-B aligned tail: (rootCode, triBase, cullBackface, -) */
     int32_t triBase;
     int32_t cullBackface; /* material.flag != GLASS (RC:355) */
     int32_t pad[5];

@@ -184,60 +184,23 @@ __device__ __forceinline__ void tri_test(const DTri* __restrict__ tris, int triI
     }
 }
 
-/* RayTriangleBVH — RC:234-287 for one model, one ray per lane. */
-template <bool STATS>
-__device__ __forceinline__ void traverse_model(const KArgs& a, uint32_t rootCode, int triBase, bool cull, rt_f3 pos, rt_f3 dir,
-                                               rt_f3 invDir, uint32_t* stackBase /* &s_stack[0][lane] */, float& bestDst,
-                                               int& bestTri, float& bu, float& bv, float& bdet, Stats& st)
-{
-    const DPair* __restrict__ pairs = a.pairs;
-    const DTri* __restrict__ tris = a.tris;
-    uint32_t cur = rootCode;
-    int sp = 0;
-    for (;;) {
-        if (cur & RT_CODE_LEAF) {
-            uint32_t count = (cur >> 24) & 0x7fu;
-            uint32_t start = cur & RT_CODE_MAX_INLINE_START;
-            if (count == 0) { /* indirect (huge leaf) */
-                count = a.bigLeaves[2 * start + 1];
-                start = a.bigLeaves[2 * start];
-            }
-            if (STATS) { st.leaf++; st.tri += count; }
-            int first = triBase + (int)start;
-            for (uint32_t i = 0; i < count; i++) tri_test(tris, first + (int)i, pos, dir, cull, bestDst, bestTri, bu, bv, bdet);
-            if (sp == 0) break;
-            cur = stackBase[(--sp) * RT_WAVE];
-        } else {
-            if (STATS) st.inner++;
-            const DPair* pr = pairs + cur;
-            const float4* q = reinterpret_cast<const float4*>(pr);
-            float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            float aMin[3] = {q0.x, q0.y, q0.z}, aMax[3] = {q0.w, q1.x, q1.y};
-            float bMin[3] = {q1.z, q1.w, q2.x}, bMax[3] = {q2.y, q2.z, q2.w};
-            uint32_t codeA = __float_as_uint(q3.x), codeB = __float_as_uint(q3.y);
-            float dstA = box_dst(pos, invDir, aMin, aMax);
-            float dstB = box_dst(pos, invDir, bMin, bMax);
-            bool isNearestA = dstA <= dstB;
-            float dstNear = isNearestA ? dstA : dstB;
-            float dstFar = isNearestA ? dstB : dstA;
-            uint32_t codeNear = isNearestA ? codeA : codeB;
-            uint32_t codeFar = isNearestA ? codeB : codeA;
-            /* RC:280-281: push far, then near; the next pop is the near child, so it
-             * stays in `cur`.  dstNear <= dstFar, so far-pushed implies near-pushed. */
-            if (dstNear < bestDst) {
-                if (dstFar < bestDst) { stackBase[sp * RT_WAVE] = codeFar; sp++; }
-                cur = codeNear;
-            } else {
-                if (sp == 0) break;
-                cur = stackBase[(--sp) * RT_WAVE];
-            }
-        }
-    }
-}
+/* ---------------------------------------------------------------------------
+ * CalculateRayCollision — RC:335-374 plus the sphere buffer hooked at RC:341,
+ * split so that a lane can SUSPEND in the middle of it (see rt_trace_kernel):
+ *   begin_intersect : result.dst = inf, all spheres, traversal state = "before model 0"
+ *   traverse        : the model loop + BVH traversal state machine, resumable
+ * ------------------------------------------------------------------------- */
+struct Trav {
+    int m;          /* current model index */
+    uint32_t cur;   /* current node code, or RT_CODE_NEXT_MODEL */
+    int sp;         /* entries on this lane's LDS stack */
+    rt_f3 lpos, ldir, linv; /* ray in the model's local space (RC:351-353) */
+    int triBase;
+    bool cull;
+};
 
-/* CalculateRayCollision — RC:335-374 plus the sphere buffer hooked at RC:341. */
 template <bool STATS>
-__device__ __forceinline__ void intersect_scene(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, SceneHit& h, Stats& st)
+__device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f3 rdir, SceneHit& h, Trav& t, Stats& st)
 {
     h.dst = RT_INF;
     h.obj = -1;
@@ -290,35 +253,119 @@ __device__ __forceinline__ void intersect_scene(const KArgs& a, rt_f3 rpos, rt_f
     }
     if (STATS) st.sphere += (uint32_t)a.nSpheres;
 
-    const RT_CAS DModel* models = (const RT_CAS DModel*)a.models;
-    for (int m = 0; m < a.nModels; m++) {
-        const RT_CAS DModel& M = models[m];
-        /* RC:351-353 */
-        rt_f3 lpos = rt_v3(M.w2l[0] * rpos.x + M.w2l[1] * rpos.y + M.w2l[2] * rpos.z + M.w2l[3] * 1.0f,
-                           M.w2l[4] * rpos.x + M.w2l[5] * rpos.y + M.w2l[6] * rpos.z + M.w2l[7] * 1.0f,
-                           M.w2l[8] * rpos.x + M.w2l[9] * rpos.y + M.w2l[10] * rpos.z + M.w2l[11] * 1.0f);
-        rt_f3 ldir = rt_v3(M.w2l[0] * rdir.x + M.w2l[1] * rdir.y + M.w2l[2] * rdir.z + M.w2l[3] * 0.0f,
-                           M.w2l[4] * rdir.x + M.w2l[5] * rdir.y + M.w2l[6] * rdir.z + M.w2l[7] * 0.0f,
-                           M.w2l[8] * rdir.x + M.w2l[9] * rdir.y + M.w2l[10] * rdir.z + M.w2l[11] * 0.0f);
-        /* invDir (RC:353) is only read by box tests: a mesh whose root is a leaf has none */
-        rt_f3 linv = rt_v3s(0.0f);
-        if (!(M.rootCode & RT_CODE_LEAF)) linv = rt_v3(1 / ldir.x, 1 / ldir.y, 1 / ldir.z);
-        float best = h.dst;
-        int bestTri = -1;
-        float bu = 0, bv = 0, bdet = 0;
-        traverse_model<STATS>(a, M.rootCode, M.triBase, M.cullBackface != 0, lpos, ldir, linv, stackBase, best, bestTri, bu, bv,
-                              bdet, st);
-        if (bestTri >= 0) { /* <=> hit.dst < result.dst (RC:362) */
-            h.dst = best;
-            h.obj = a.nSpheres + m;
-            h.tri = bestTri;
-            h.u = bu;
-            h.v = bv;
-            h.det = bdet;
-            h.backface = bdet < 0;
+    t.m = -1;
+    t.cur = RT_CODE_NEXT_MODEL;
+    t.sp = 0;
+    t.lpos = t.ldir = t.linv = rt_v3s(0.0f);
+    t.triBase = 0;
+    t.cull = true;
+}
+
+/* Model loop (RC:347-371) and per-model BVH traversal (RayTriangleBVH, RC:234-287) as
+ * ONE per-lane state machine.  The reference nests them, which on a SIMD machine makes
+ * every lane wait, model after model, for the slowest traversal in the wave.  Here each
+ * lane walks its own (model, node) sequence — the order of box tests, triangle tests
+ * and strict-'<' updates of a given ray is exactly the reference's — and the wave only
+ * re-converges by kind of work ("while-while"):
+ *   A  lanes that finished a model load the next one and transform the ray (RC:351-353);
+ *   B  lanes at an inner node step down until they reach a leaf or run out of nodes;
+ *   C  lanes at a leaf test its triangles.
+ * h.dst is result.dst carried from model to model (rayLength = result.dst, RC:359).
+ *
+ * Returns true when this lane has visited every model.  With SUSPEND the wave leaves
+ * the loop as soon as at most half of the lanes that entered are still traversing;
+ * the stragglers keep their state in `t`/`h`/LDS and resume at the next call. */
+template <bool STATS, bool SUSPEND>
+__device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, SceneHit& h, Trav& t, Stats& st)
+{
+    const DModel* __restrict__ models = a.models;
+    const DPair* __restrict__ pairs = a.pairs;
+    const DTri* __restrict__ tris = a.tris;
+    const int entered = SUSPEND ? __popcll(__ballot(1)) : 0;
+    bool finished = false;
+    for (;;) {
+        if (t.cur == RT_CODE_NEXT_MODEL) { /* ---- A */
+            t.m++;
+            if (t.m >= a.nModels) { finished = true; break; }
+            if (STATS) st.model++;
+            const float4* q = reinterpret_cast<const float4*>(models + t.m);
+            const float4 r0 = q[0], r1 = q[1], r2 = q[2];
+            const float4 tail = q[6];
+            t.lpos = rt_v3(r0.x * rpos.x + r0.y * rpos.y + r0.z * rpos.z + r0.w * 1.0f,
+                           r1.x * rpos.x + r1.y * rpos.y + r1.z * rpos.z + r1.w * 1.0f,
+                           r2.x * rpos.x + r2.y * rpos.y + r2.z * rpos.z + r2.w * 1.0f);
+            t.ldir = rt_v3(r0.x * rdir.x + r0.y * rdir.y + r0.z * rdir.z + r0.w * 0.0f,
+                           r1.x * rdir.x + r1.y * rdir.y + r1.z * rdir.z + r1.w * 0.0f,
+                           r2.x * rdir.x + r2.y * rdir.y + r2.z * rdir.z + r2.w * 0.0f);
+            t.cur = __float_as_uint(tail.x);
+            t.triBase = (int)__float_as_uint(tail.y);
+            t.cull = __float_as_uint(tail.z) != 0;
+            t.sp = 0;
+            /* invDir (RC:353) is only read by box tests: a mesh whose root is a leaf has none */
+            if (!(t.cur & RT_CODE_LEAF)) t.linv = rt_v3(1 / t.ldir.x, 1 / t.ldir.y, 1 / t.ldir.z);
+        }
+        while (!(t.cur & RT_CODE_LEAF) && t.cur != RT_CODE_NEXT_MODEL) { /* ---- B: RC:262-282 */
+            if (STATS) st.inner++;
+            const float4* q = reinterpret_cast<const float4*>(pairs + t.cur);
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            float aMin[3] = {q0.x, q0.y, q0.z}, aMax[3] = {q0.w, q1.x, q1.y};
+            float bMin[3] = {q1.z, q1.w, q2.x}, bMax[3] = {q2.y, q2.z, q2.w};
+            uint32_t codeA = __float_as_uint(q3.x), codeB = __float_as_uint(q3.y);
+            float dstA = box_dst(t.lpos, t.linv, aMin, aMax);
+            float dstB = box_dst(t.lpos, t.linv, bMin, bMax);
+            bool isNearestA = dstA <= dstB;
+            float dstNear = isNearestA ? dstA : dstB;
+            float dstFar = isNearestA ? dstB : dstA;
+            uint32_t codeNear = isNearestA ? codeA : codeB;
+            uint32_t codeFar = isNearestA ? codeB : codeA;
+            /* RC:280-281: push far, then near; the next pop is the near child, so it stays
+             * in `cur`.  dstNear <= dstFar, so far-pushed implies near-pushed. */
+            if (dstNear < h.dst) {
+                if (dstFar < h.dst) { stackBase[t.sp * RT_WAVE] = codeFar; t.sp++; }
+                t.cur = codeNear;
+            } else if (t.sp == 0) {
+                t.cur = RT_CODE_NEXT_MODEL;
+            } else {
+                t.cur = stackBase[(--t.sp) * RT_WAVE];
+            }
+        }
+        if (t.cur & RT_CODE_LEAF) { /* ---- C: RC:248-261 */
+            uint32_t count = (t.cur >> 24) & 0x7fu;
+            uint32_t start = t.cur & RT_CODE_MAX_INLINE_START;
+            if (count == 0) { /* indirect (oversized leaf) */
+                count = a.bigLeaves[2 * start + 1];
+                start = a.bigLeaves[2 * start];
+            }
+            if (STATS) { st.leaf++; st.tri += count; }
+            const int first = t.triBase + (int)start;
+            for (uint32_t i = 0; i < count; i++) {
+                const float before = h.dst;
+                tri_test(tris, first + (int)i, t.lpos, t.ldir, t.cull, h.dst, h.tri, h.u, h.v, h.det);
+                if (h.dst < before) { /* RC:362-369 (an update strictly lowers dst) */
+                    h.obj = a.nSpheres + t.m;
+                    h.backface = h.det < 0;
+                }
+            }
+            if (t.sp == 0) t.cur = RT_CODE_NEXT_MODEL;
+            else t.cur = stackBase[(--t.sp) * RT_WAVE];
+        }
+        if (SUSPEND) {
+            /* lanes still here = lanes still traversing; leave together once at least half of
+             * the entrants are done (they wait outside for shading) */
+            const int active = __popcll(__ballot(1));
+            if (active * 2 <= entered) break;
         }
     }
-    if (STATS) st.model += (uint32_t)a.nModels;
+    return finished;
+}
+
+/* Run-to-completion form (debug hook). */
+template <bool STATS>
+__device__ __forceinline__ void intersect_scene(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, SceneHit& h, Stats& st)
+{
+    Trav t;
+    begin_intersect<STATS>(a, rpos, rdir, h, t, st);
+    traverse<STATS, false>(a, rpos, rdir, stackBase, h, t, st);
 }
 
 /* Position and world normal of the winning hit: RC:319-320 (sphere) or RC:208-209 +
@@ -349,10 +396,25 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+/* ---------------------------------------------------------------------------
+ * The trace kernel: RayTrace (RCC:10-24) -> RayTrace(uv) (RC:545-582) -> Trace (RC:479-542).
+ *
+ * One wave64 per 8x8 tile, one lane per pixel.  A lane is a small state machine over
+ * its pixel's serial work (quirk Q13: one RNG chain per pixel per frame):
+ *     [frame finished?] -> camera ray -> { spheres -> models/BVH -> shade } per bounce ...
+ * and the wave regroups lanes by what they need next instead of following the
+ * reference's nested loops:
+ *   - a lane whose path ended starts its pixel's next sample at once;
+ *   - lanes enter the traversal loop together but leave it as soon as half of them are
+ *     done; the rest stay suspended inside their traversal (state in registers + LDS
+ *     stack) while the finished ones shade, bounce and re-enter with their next ray.
+ * LDS: the per-lane traversal stack, [level][lane], sized by the host to the deepest
+ * BVH of the scene (dynamic shared memory).
+ * ------------------------------------------------------------------------- */
 template <bool STATS>
 __global__ void __launch_bounds__(RT_WAVE) rt_trace_kernel(const KArgs a)
 {
-    __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_WAVE];
+    extern __shared__ uint32_t s_stack[];
     const int lane = threadIdx.x;
     uint32_t* stackBase = &s_stack[lane];
 
@@ -369,9 +431,7 @@ __global__ void __launch_bounds__(RT_WAVE) rt_trace_kernel(const KArgs a)
     const float uvx = (float)(uint32_t)x / ((float)a.W - 1.0f);
     const float uvy = (float)(uint32_t)y / ((float)a.H - 1.0f);
     /* RC:547-558 */
-    const rt_f3 camOrigin = rt_v3(a.cam[0] * 0.0f + a.cam[4] * 0.0f + a.cam[8] * 0.0f + a.cam[12] * 1.0f,
-                                  a.cam[1] * 0.0f + a.cam[5] * 0.0f + a.cam[9] * 0.0f + a.cam[13] * 1.0f,
-                                  a.cam[2] * 0.0f + a.cam[6] * 0.0f + a.cam[10] * 0.0f + a.cam[14] * 1.0f);
+    const rt_f3 camOrigin = rt_mul_point(a.cam, rt_v3(0.0f, 0.0f, 0.0f), 1.0f);
     const uint32_t pixelCoordX = (uint32_t)(uvx * (float)a.W);
     const uint32_t pixelCoordY = (uint32_t)(uvy * (float)a.H);
     const uint32_t pixelIndex = pixelCoordY * a.W + pixelCoordX;
@@ -389,59 +449,70 @@ __global__ void __launch_bounds__(RT_WAVE) rt_trace_kernel(const KArgs a)
     int sample = 0;
     rt_f3 totalIncoming = rt_v3s(0.0f);
 
-    bool pathActive = false;
+    bool pathActive = false; /* a ray is waiting to be intersected / is being intersected */
+    bool inTrav = false;     /* suspended inside traverse() */
     int bounce = 0;
     rt_f3 rpos = rt_v3s(0.0f), rdir = rt_v3s(0.0f), transmittance = rt_v3s(0.0f), pathLight = rt_v3s(0.0f);
+    SceneHit h;
+    Trav t;
+    h.dst = RT_INF; h.obj = -1; h.tri = -1; h.u = h.v = h.det = 0.0f; h.backface = false;
+    t.m = 0; t.cur = RT_CODE_NEXT_MODEL; t.sp = 0; t.lpos = t.ldir = t.linv = rt_v3s(0.0f); t.triBase = 0; t.cull = true;
     uint32_t segments = 0;
     Stats st = {0, 0, 0, 0, 0};
     if (a.nFrames <= 0) laneDone = true;
 
     while (!laneDone) {
-        if (!pathActive) {
-            if (sample == a.spp) {
-                /* RC:581 + RCC:18-23: finish this frame of this pixel */
-                rt_f3 col = totalIncoming / (float)a.spp;
-                if (frame == frameEnd - 1) {
-                    float4 o = make_float4(col.x, col.y, col.z, 1.0f);
-                    *reinterpret_cast<float4*>(a.frameRender + pixOff) = o;
+        if (!inTrav) {
+            if (!pathActive) {
+                if (sample == a.spp) {
+                    /* RC:581 + RCC:18-23: finish this frame of this pixel */
+                    rt_f3 col = totalIncoming / (float)a.spp;
+                    if (frame == frameEnd - 1) {
+                        float4 o = make_float4(col.x, col.y, col.z, 1.0f);
+                        *reinterpret_cast<float4*>(a.frameRender + pixOff) = o;
+                    }
+                    if (a.accumulate) {
+                        float4 acc = *reinterpret_cast<float4*>(a.accumulated + pixOff);
+                        acc.x += col.x;
+                        acc.y += col.y;
+                        acc.z += col.z;
+                        acc.w += 1.0f;
+                        *reinterpret_cast<float4*>(a.accumulated + pixOff) = acc;
+                    }
+                    frame++;
+                    if (frame == frameEnd) {
+                        laneDone = true;
+                    } else {
+                        rng = pixelIndex + (uint32_t)frame * 719393u + (uint32_t)a.seed;
+                        sample = 0;
+                        totalIncoming = rt_v3s(0.0f);
+                    }
                 }
-                if (a.accumulate) {
-                    float4 acc = *reinterpret_cast<float4*>(a.accumulated + pixOff);
-                    acc.x += col.x;
-                    acc.y += col.y;
-                    acc.z += col.z;
-                    acc.w += 1.0f;
-                    *reinterpret_cast<float4*>(a.accumulated + pixOff) = acc;
-                }
-                frame++;
-                if (frame == frameEnd) {
-                    laneDone = true;
-                } else {
-                    rng = pixelIndex + (uint32_t)frame * 719393u + (uint32_t)a.seed;
-                    sample = 0;
-                    totalIncoming = rt_v3s(0.0f);
+                if (!laneDone && sample < a.spp) {
+                    /* RC:565-576: next camera ray of this pixel */
+                    rt_f2 dj = rand_circle(&rng);
+                    rt_f3 rayOrigin = camOrigin + camRight * (dj.x * a.defocus / numPixelsX) + camUp * (dj.y * a.defocus / numPixelsX);
+                    rt_f2 jj = rand_circle(&rng);
+                    rt_f3 jfp = focusPoint + camRight * (jj.x * a.diverge / numPixelsX) + camUp * (jj.y * a.diverge / numPixelsX);
+                    rpos = rayOrigin;
+                    rdir = rt_normalize(jfp - rayOrigin);
+                    transmittance = rt_v3s(1.0f);
+                    pathLight = rt_v3s(0.0f);
+                    bounce = 0;
+                    sample++;
+                    if (a.maxBounce >= 0) pathActive = true;                /* RC:485: the loop runs for i = 0 */
+                    else totalIncoming = totalIncoming + rt_v3s(0.0f);      /* Trace returned 0 (RC:578) */
                 }
             }
-            if (!laneDone && sample < a.spp) {
-                /* RC:565-576: next camera ray of this pixel */
-                rt_f2 dj = rand_circle(&rng);
-                rt_f3 rayOrigin = camOrigin + camRight * (dj.x * a.defocus / numPixelsX) + camUp * (dj.y * a.defocus / numPixelsX);
-                rt_f2 jj = rand_circle(&rng);
-                rt_f3 jfp = focusPoint + camRight * (jj.x * a.diverge / numPixelsX) + camUp * (jj.y * a.diverge / numPixelsX);
-                rpos = rayOrigin;
-                rdir = rt_normalize(jfp - rayOrigin);
-                transmittance = rt_v3s(1.0f);
-                pathLight = rt_v3s(0.0f);
-                bounce = 0;
-                pathActive = true;
-                sample++;
+            if (pathActive) {
+                begin_intersect<STATS>(a, rpos, rdir, h, t, st);
+                segments++;
+                inTrav = true;
             }
         }
-        if (pathActive) {
-            /* one iteration of Trace's bounce loop — RC:485-539 */
-            SceneHit h;
-            intersect_scene<STATS>(a, rpos, rdir, stackBase, h, st);
-            segments++;
+        if (inTrav && traverse<STATS, true>(a, rpos, rdir, stackBase, h, t, st)) {
+            inTrav = false;
+            /* the rest of one iteration of Trace's bounce loop — RC:488-538 */
             bool endPath = false;
             if (h.obj < 0) {
                 if (a.useSky) pathLight = pathLight + transmittance * environment_light(a, rdir);
