@@ -724,6 +724,24 @@ int rt_get_counters(RtContext* ctx, RtCounters* out)
 }
 
 /* ---- test hooks ------------------------------------------------------------ */
+/* Wave-level phase profile of the stats launches since rt_reset_counters:
+ * out[2*p] = times a wave executed phase p, out[2*p+1] = lanes active in it
+ * (p: 0 loop, 1 raygen, 2 spheres, 3 traverse call, 4 model setup, 5 inner step,
+ *  6 triangle test, 7 shade hit, 8 sky). */
+int rt_debug_phase_profile(RtContext* ctx, uint64_t* out, int n)
+{
+    if (!ctx || !out || n < 2 * RT_N_PHASES) return fail(ctx, RT_ERR_INVALID_ARG, "rt_debug_phase_profile: need %d entries", 2 * RT_N_PHASES);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned long long> h((size_t)RT_COUNTER_SLOTS * RT_COUNTER_FIELDS);
+    HIP_TRY(ctx, hipMemcpy(h.data(), ctx->dCounters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int f = 0; f < 2 * RT_N_PHASES; f++) {
+        out[f] = 0;
+        for (int s = 0; s < RT_COUNTER_SLOTS; s++) out[f] += h[(size_t)s * RT_COUNTER_FIELDS + 8 + f];
+    }
+    return RT_OK;
+}
+
 int rt_debug_intersect(RtContext* ctx, const float* origins, const float* dirs, int n, float* out10)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");

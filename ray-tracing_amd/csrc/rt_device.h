@@ -29,7 +29,8 @@
 #define RT_WAVE 64
 #define RT_STACK_DEPTH 34            /* >= RT_MAX_BVH_DEPTH + 2 */
 #define RT_COUNTER_SLOTS 1024        /* counters are spread over slots to avoid same-address atomics */
-#define RT_COUNTER_FIELDS 8
+#define RT_N_PHASES 9
+#define RT_COUNTER_FIELDS (8 + 2 * RT_N_PHASES)
 
 /* node codes: bit31 = leaf.  leaf: [30:24] = triangle count (1..127), [23:0] = first
  * triangle (relative to the model's triOffset); count field 0 = indirect, [23:0]

@@ -31,6 +31,16 @@
 #include "../../include/rt_math.h"
 #include "rt_device.h"
 
+/* waves per SIMD the register allocator must leave room for (launch_bounds 2nd argument) */
+/* traverse() is left once active <= entered * NUM/DEN lanes are still traversing */
+#ifndef RT_SUSPEND_NUM
+#define RT_SUSPEND_NUM 1
+#define RT_SUSPEND_DEN 4
+#endif
+#ifndef RT_MIN_WAVES_PER_SIMD
+#define RT_MIN_WAVES_PER_SIMD 5
+#endif
+
 namespace rtk {
 
 /* Scene constants (spheres, models) are indexed wave-uniformly and never written
@@ -68,7 +78,20 @@ struct SceneHit {
 
 struct Stats {
     uint32_t inner, leaf, tri, sphere, model;
+    /* wave-level phase profile (stats launches only): how often the wave executed a phase
+     * and how many lanes were active in it — lane utilisation per phase = lanes / (64 * execs) */
+    uint32_t phExec[RT_N_PHASES], phLanes[RT_N_PHASES];
 };
+enum { PH_LOOP = 0, PH_RAYGEN, PH_SPHERES, PH_TRAVERSE_CALL, PH_MODEL, PH_INNER, PH_TRI, PH_SHADE_HIT, PH_SKY };
+template <bool STATS>
+__device__ __forceinline__ void phase_mark(Stats& st, int ph)
+{
+    if (STATS) {
+        const unsigned long long m = __ballot(1);
+        st.phLanes[ph]++;
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) st.phExec[ph]++;
+    }
+}
 
 /* RandomValueNormalDistribution / RandomDirection — RC:141-157 */
 __device__ __forceinline__ float rand_normal(uint32_t* state)
@@ -191,9 +214,11 @@ __device__ __forceinline__ void tri_test(const DTri* __restrict__ tris, int triI
  *   traverse        : the model loop + BVH traversal state machine, resumable
  * ------------------------------------------------------------------------- */
 struct Trav {
+    unsigned long long cand; /* models [0,64) still to visit (bit m), from the lockstep root filter */
     int m;          /* current model index */
     uint32_t cur;   /* current node code, or RT_CODE_NEXT_MODEL */
     int sp;         /* entries on this lane's LDS stack */
+    bool rootStep;  /* the next inner step is the model's root (already counted by the filter) */
     rt_f3 lpos, ldir, linv; /* ray in the model's local space (RC:351-353) */
     int triBase;
     bool cull;
@@ -253,9 +278,46 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
     }
     if (STATS) st.sphere += (uint32_t)a.nSpheres;
 
+    /* Root filter, in lockstep over the models (wave-uniform loop, matrices and the root's
+     * child boxes in SGPRs): transform the ray (RC:351-353) and run the root's two box tests
+     * (RC:269-270).  A model whose root children are both missed — or both farther than the
+     * closest sphere hit, result.dst only ever shrinks — contributes nothing in the reference
+     * (nothing is pushed, RC:280-281), so only the others are handed to the per-lane traversal,
+     * which redoes the same arithmetic for them in model order.  The reference's root step is
+     * still counted for every model. */
+    unsigned long long cand = 0;
+    const RT_CAS DModel* cm = (const RT_CAS DModel*)a.models;
+    const RT_CAS DPair* cp = (const RT_CAS DPair*)a.pairs;
+    const int nf = a.nModels < 64 ? a.nModels : 64;
+    for (int m = 0; m < nf; m++) {
+        const RT_CAS DModel& M = cm[m];
+        const uint32_t root = M.rootCode;
+        bool keep = true;
+        if (!(root & RT_CODE_LEAF)) {
+            rt_f3 lpos = rt_v3(M.w2l[0] * rpos.x + M.w2l[1] * rpos.y + M.w2l[2] * rpos.z + M.w2l[3] * 1.0f,
+                               M.w2l[4] * rpos.x + M.w2l[5] * rpos.y + M.w2l[6] * rpos.z + M.w2l[7] * 1.0f,
+                               M.w2l[8] * rpos.x + M.w2l[9] * rpos.y + M.w2l[10] * rpos.z + M.w2l[11] * 1.0f);
+            rt_f3 ldir = rt_v3(M.w2l[0] * rdir.x + M.w2l[1] * rdir.y + M.w2l[2] * rdir.z + M.w2l[3] * 0.0f,
+                               M.w2l[4] * rdir.x + M.w2l[5] * rdir.y + M.w2l[6] * rdir.z + M.w2l[7] * 0.0f,
+                               M.w2l[8] * rdir.x + M.w2l[9] * rdir.y + M.w2l[10] * rdir.z + M.w2l[11] * 0.0f);
+            rt_f3 linv = rt_v3(1 / ldir.x, 1 / ldir.y, 1 / ldir.z);
+            const RT_CAS DPair& P = cp[root];
+            float aMin[3] = {P.aMin[0], P.aMin[1], P.aMin[2]}, aMax[3] = {P.aMax[0], P.aMax[1], P.aMax[2]};
+            float bMin[3] = {P.bMin[0], P.bMin[1], P.bMin[2]}, bMax[3] = {P.bMax[0], P.bMax[1], P.bMax[2]};
+            float dstA = box_dst(lpos, linv, aMin, aMax);
+            float dstB = box_dst(lpos, linv, bMin, bMax);
+            keep = (dstA < h.dst) || (dstB < h.dst);
+            if (STATS) st.inner++;
+        }
+        cand |= (keep ? 1ull : 0ull) << m;
+    }
+    if (STATS) st.model += (uint32_t)a.nModels;
+
+    t.cand = cand;
     t.m = -1;
     t.cur = RT_CODE_NEXT_MODEL;
     t.sp = 0;
+    t.rootStep = false;
     t.lpos = t.ldir = t.linv = rt_v3s(0.0f);
     t.triBase = 0;
     t.cull = true;
@@ -282,54 +344,76 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
     const DPair* __restrict__ pairs = a.pairs;
     const DTri* __restrict__ tris = a.tris;
     const int entered = SUSPEND ? __popcll(__ballot(1)) : 0;
+    phase_mark<STATS>(st, PH_TRAVERSE_CALL);
     bool finished = false;
     for (;;) {
-        if (t.cur == RT_CODE_NEXT_MODEL) { /* ---- A */
-            t.m++;
-            if (t.m >= a.nModels) { finished = true; break; }
-            if (STATS) st.model++;
-            const float4* q = reinterpret_cast<const float4*>(models + t.m);
-            const float4 r0 = q[0], r1 = q[1], r2 = q[2];
-            const float4 tail = q[6];
-            t.lpos = rt_v3(r0.x * rpos.x + r0.y * rpos.y + r0.z * rpos.z + r0.w * 1.0f,
-                           r1.x * rpos.x + r1.y * rpos.y + r1.z * rpos.z + r1.w * 1.0f,
-                           r2.x * rpos.x + r2.y * rpos.y + r2.z * rpos.z + r2.w * 1.0f);
-            t.ldir = rt_v3(r0.x * rdir.x + r0.y * rdir.y + r0.z * rdir.z + r0.w * 0.0f,
-                           r1.x * rdir.x + r1.y * rdir.y + r1.z * rdir.z + r1.w * 0.0f,
-                           r2.x * rdir.x + r2.y * rdir.y + r2.z * rdir.z + r2.w * 0.0f);
-            t.cur = __float_as_uint(tail.x);
-            t.triBase = (int)__float_as_uint(tail.y);
-            t.cull = __float_as_uint(tail.z) != 0;
-            t.sp = 0;
-            /* invDir (RC:353) is only read by box tests: a mesh whose root is a leaf has none */
-            if (!(t.cur & RT_CODE_LEAF)) t.linv = rt_v3(1 / t.ldir.x, 1 / t.ldir.y, 1 / t.ldir.z);
-        }
-        while (!(t.cur & RT_CODE_LEAF) && t.cur != RT_CODE_NEXT_MODEL) { /* ---- B: RC:262-282 */
-            if (STATS) st.inner++;
-            const float4* q = reinterpret_cast<const float4*>(pairs + t.cur);
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            float aMin[3] = {q0.x, q0.y, q0.z}, aMax[3] = {q0.w, q1.x, q1.y};
-            float bMin[3] = {q1.z, q1.w, q2.x}, bMax[3] = {q2.y, q2.z, q2.w};
-            uint32_t codeA = __float_as_uint(q3.x), codeB = __float_as_uint(q3.y);
-            float dstA = box_dst(t.lpos, t.linv, aMin, aMax);
-            float dstB = box_dst(t.lpos, t.linv, bMin, bMax);
-            bool isNearestA = dstA <= dstB;
-            float dstNear = isNearestA ? dstA : dstB;
-            float dstFar = isNearestA ? dstB : dstA;
-            uint32_t codeNear = isNearestA ? codeA : codeB;
-            uint32_t codeFar = isNearestA ? codeB : codeA;
-            /* RC:280-281: push far, then near; the next pop is the near child, so it stays
-             * in `cur`.  dstNear <= dstFar, so far-pushed implies near-pushed. */
-            if (dstNear < h.dst) {
-                if (dstFar < h.dst) { stackBase[t.sp * RT_WAVE] = codeFar; t.sp++; }
-                t.cur = codeNear;
-            } else if (t.sp == 0) {
-                t.cur = RT_CODE_NEXT_MODEL;
-            } else {
-                t.cur = stackBase[(--t.sp) * RT_WAVE];
+        /* One kind of work per iteration, chosen for the whole wave: the kind most lanes are
+         * waiting for (wave-uniform branch, so only that code is issued).  A lane deep inside
+         * a big mesh no longer drags 60 idle lanes through its private box tests: it advances
+         * whenever "inner step" is the majority need (every model's root step is one), and
+         * otherwise waits, keeping its state. */
+        const bool atNext = t.cur == RT_CODE_NEXT_MODEL;
+        const bool atLeaf = (t.cur & RT_CODE_LEAF) != 0;
+        const bool atInner = !atNext && !atLeaf;
+        const int nA = __popcll(__ballot(atNext)), nB = __popcll(__ballot(atInner)), nC = __popcll(__ballot(atLeaf));
+        if (nA >= nB && nA >= nC) {
+            if (atNext) { /* ---- A: next model, RC:349-355 */
+                /* next model: the filtered candidates among [0,64), then any model >= 64 in order */
+                if (t.cand) {
+                    t.m = __ffsll((long long)t.cand) - 1;
+                    t.cand &= t.cand - 1;
+                } else {
+                    t.m = t.m < 63 ? 64 : t.m + 1;
+                    if (t.m >= a.nModels) { finished = true; break; }
+                    if (STATS && !(models[t.m].rootCode & RT_CODE_LEAF)) st.inner++;
+                }
+                t.rootStep = true;
+                phase_mark<STATS>(st, PH_MODEL);
+                const float4* q = reinterpret_cast<const float4*>(models + t.m);
+                const float4 r0 = q[0], r1 = q[1], r2 = q[2];
+                const float4 tail = q[6];
+                t.lpos = rt_v3(r0.x * rpos.x + r0.y * rpos.y + r0.z * rpos.z + r0.w * 1.0f,
+                               r1.x * rpos.x + r1.y * rpos.y + r1.z * rpos.z + r1.w * 1.0f,
+                               r2.x * rpos.x + r2.y * rpos.y + r2.z * rpos.z + r2.w * 1.0f);
+                t.ldir = rt_v3(r0.x * rdir.x + r0.y * rdir.y + r0.z * rdir.z + r0.w * 0.0f,
+                               r1.x * rdir.x + r1.y * rdir.y + r1.z * rdir.z + r1.w * 0.0f,
+                               r2.x * rdir.x + r2.y * rdir.y + r2.z * rdir.z + r2.w * 0.0f);
+                t.cur = __float_as_uint(tail.x);
+                t.triBase = (int)__float_as_uint(tail.y);
+                t.cull = __float_as_uint(tail.z) != 0;
+                t.sp = 0;
+                /* invDir (RC:353) is only read by box tests: a mesh whose root is a leaf has none */
+                if (!(t.cur & RT_CODE_LEAF)) t.linv = rt_v3(1 / t.ldir.x, 1 / t.ldir.y, 1 / t.ldir.z);
             }
-        }
-        if (t.cur & RT_CODE_LEAF) { /* ---- C: RC:248-261 */
+        } else if (nB >= nC) {
+            if (atInner) { /* ---- B: one inner node, RC:262-282 */
+                if (STATS && !t.rootStep) st.inner++;
+                t.rootStep = false;
+                phase_mark<STATS>(st, PH_INNER);
+                const float4* q = reinterpret_cast<const float4*>(pairs + t.cur);
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                float aMin[3] = {q0.x, q0.y, q0.z}, aMax[3] = {q0.w, q1.x, q1.y};
+                float bMin[3] = {q1.z, q1.w, q2.x}, bMax[3] = {q2.y, q2.z, q2.w};
+                uint32_t codeA = __float_as_uint(q3.x), codeB = __float_as_uint(q3.y);
+                float dstA = box_dst(t.lpos, t.linv, aMin, aMax);
+                float dstB = box_dst(t.lpos, t.linv, bMin, bMax);
+                bool isNearestA = dstA <= dstB;
+                float dstNear = isNearestA ? dstA : dstB;
+                float dstFar = isNearestA ? dstB : dstA;
+                uint32_t codeNear = isNearestA ? codeA : codeB;
+                uint32_t codeFar = isNearestA ? codeB : codeA;
+                /* RC:280-281: push far, then near; the next pop is the near child, so it stays
+                 * in `cur`.  dstNear <= dstFar, so far-pushed implies near-pushed. */
+                if (dstNear < h.dst) {
+                    if (dstFar < h.dst) { stackBase[t.sp * RT_WAVE] = codeFar; t.sp++; }
+                    t.cur = codeNear;
+                } else if (t.sp == 0) {
+                    t.cur = RT_CODE_NEXT_MODEL;
+                } else {
+                    t.cur = stackBase[(--t.sp) * RT_WAVE];
+                }
+            }
+        } else if (atLeaf) { /* ---- C: one leaf, RC:248-261 */
             uint32_t count = (t.cur >> 24) & 0x7fu;
             uint32_t start = t.cur & RT_CODE_MAX_INLINE_START;
             if (count == 0) { /* indirect (oversized leaf) */
@@ -339,6 +423,7 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
             if (STATS) { st.leaf++; st.tri += count; }
             const int first = t.triBase + (int)start;
             for (uint32_t i = 0; i < count; i++) {
+                phase_mark<STATS>(st, PH_TRI);
                 const float before = h.dst;
                 tri_test(tris, first + (int)i, t.lpos, t.ldir, t.cull, h.dst, h.tri, h.u, h.v, h.det);
                 if (h.dst < before) { /* RC:362-369 (an update strictly lowers dst) */
@@ -353,7 +438,7 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
             /* lanes still here = lanes still traversing; leave together once at least half of
              * the entrants are done (they wait outside for shading) */
             const int active = __popcll(__ballot(1));
-            if (active * 2 <= entered) break;
+            if (active * RT_SUSPEND_DEN <= entered * RT_SUSPEND_NUM) break;
         }
     }
     return finished;
@@ -412,7 +497,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
  * BVH of the scene (dynamic shared memory).
  * ------------------------------------------------------------------------- */
 template <bool STATS>
-__global__ void __launch_bounds__(RT_WAVE) rt_trace_kernel(const KArgs a)
+__global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kernel(const KArgs a)
 {
     extern __shared__ uint32_t s_stack[];
     const int lane = threadIdx.x;
@@ -456,12 +541,13 @@ __global__ void __launch_bounds__(RT_WAVE) rt_trace_kernel(const KArgs a)
     SceneHit h;
     Trav t;
     h.dst = RT_INF; h.obj = -1; h.tri = -1; h.u = h.v = h.det = 0.0f; h.backface = false;
-    t.m = 0; t.cur = RT_CODE_NEXT_MODEL; t.sp = 0; t.lpos = t.ldir = t.linv = rt_v3s(0.0f); t.triBase = 0; t.cull = true;
+    t.cand = 0; t.rootStep = false; t.m = 0; t.cur = RT_CODE_NEXT_MODEL; t.sp = 0; t.lpos = t.ldir = t.linv = rt_v3s(0.0f); t.triBase = 0; t.cull = true;
     uint32_t segments = 0;
-    Stats st = {0, 0, 0, 0, 0};
+    Stats st = {};
     if (a.nFrames <= 0) laneDone = true;
 
     while (!laneDone) {
+        phase_mark<STATS>(st, PH_LOOP);
         if (!inTrav) {
             if (!pathActive) {
                 if (sample == a.spp) {
@@ -490,6 +576,7 @@ __global__ void __launch_bounds__(RT_WAVE) rt_trace_kernel(const KArgs a)
                 }
                 if (!laneDone && sample < a.spp) {
                     /* RC:565-576: next camera ray of this pixel */
+                    phase_mark<STATS>(st, PH_RAYGEN);
                     rt_f2 dj = rand_circle(&rng);
                     rt_f3 rayOrigin = camOrigin + camRight * (dj.x * a.defocus / numPixelsX) + camUp * (dj.y * a.defocus / numPixelsX);
                     rt_f2 jj = rand_circle(&rng);
@@ -505,6 +592,7 @@ __global__ void __launch_bounds__(RT_WAVE) rt_trace_kernel(const KArgs a)
                 }
             }
             if (pathActive) {
+                phase_mark<STATS>(st, PH_SPHERES);
                 begin_intersect<STATS>(a, rpos, rdir, h, t, st);
                 segments++;
                 inTrav = true;
@@ -515,10 +603,12 @@ __global__ void __launch_bounds__(RT_WAVE) rt_trace_kernel(const KArgs a)
             /* the rest of one iteration of Trace's bounce loop — RC:488-538 */
             bool endPath = false;
             if (h.obj < 0) {
+                phase_mark<STATS>(st, PH_SKY);
                 if (a.useSky) pathLight = pathLight + transmittance * environment_light(a, rdir);
                 endPath = true;
             } else {
                 /* resolve the winner: position, normal, material */
+                phase_mark<STATS>(st, PH_SHADE_HIT);
                 rt_f3 hpos, normal;
                 resolve_hit(a, rpos, rdir, h, hpos, normal);
                 const DMaterial mat = a.materials[h.obj];
@@ -586,6 +676,13 @@ __global__ void __launch_bounds__(RT_WAVE) rt_trace_kernel(const KArgs a)
             atomicAdd(slot + 4, (unsigned long long)sp);
             atomicAdd(slot + 5, (unsigned long long)md);
         }
+        for (int p = 0; p < RT_N_PHASES; p++) {
+            uint32_t e = wave_sum(st.phExec[p]), l = wave_sum(st.phLanes[p]);
+            if (lane == 0) {
+                atomicAdd(slot + 8 + 2 * p, (unsigned long long)e);
+                atomicAdd(slot + 9 + 2 * p, (unsigned long long)l);
+            }
+        }
     } else if (lane == 0) {
         atomicAdd(slot + 0, (unsigned long long)segSum);
     }
@@ -600,7 +697,7 @@ __global__ void __launch_bounds__(RT_WAVE) rt_debug_intersect_kernel(const KArgs
     rt_f3 o = rt_v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
     rt_f3 d = rt_v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
     SceneHit h;
-    Stats st = {0, 0, 0, 0, 0};
+    Stats st = {};
     intersect_scene<false>(a, o, d, &s_stack[threadIdx.x], h, st);
     float* r = out + 10 * i;
     for (int k = 0; k < 10; k++) r[k] = 0.0f;

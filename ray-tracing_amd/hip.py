@@ -11,7 +11,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libraytrace_hip.so")
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "lib", "libraytrace_hip.so")  # RT_HIP_LIB: A/B builds
 
 # every symbol include/rt_abi.h declares (tests check the library exports them all)
 ABI_SYMBOLS = [
@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "rt_update_spheres", "rt_set_params", "rt_reset_accumulation", "rt_render_frame", "rt_render_frames",
     "rt_synchronize", "rt_get_frame", "rt_read_frame", "rt_read_accumulated", "rt_timer_begin", "rt_timer_end",
     "rt_enable_stats", "rt_reset_counters", "rt_get_counters", "rt_build_bvh", "rt_camera_view_params", "rt_version",
-    "rt_debug_intersect", "rt_debug_math_eval",
+    "rt_debug_intersect", "rt_debug_math_eval", "rt_debug_phase_profile",
 ]
 
 
@@ -39,6 +39,7 @@ class HipApi(abi.CApi):
         "enable_stats": (C.c_int, [C.c_void_p, C.c_int]),
         "debug_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
         "debug_math_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+        "debug_phase_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     }
 
     def __init__(self, path=LIB_PATH):
@@ -101,6 +102,13 @@ class HipTracer(abi.Tracer):
         out = np.zeros((len(o), 10), dtype=np.float32)
         self._check(self.api.debug_intersect(self.h, o.ctypes.data, d.ctypes.data, len(o), out.ctypes.data))
         return out
+
+    PHASES = ["loop", "raygen", "spheres", "traverse_call", "model", "inner", "tri", "shade_hit", "sky"]
+
+    def phase_profile(self):
+        out = np.zeros(2 * len(self.PHASES), dtype=np.uint64)
+        self._check(self.api.debug_phase_profile(self.h, out.ctypes.data, len(out)))
+        return {p: (int(out[2 * i]), int(out[2 * i + 1])) for i, p in enumerate(self.PHASES)}
 
     def debug_math_eval(self, op, x, y=None):
         x = np.ascontiguousarray(x, dtype=np.float32)

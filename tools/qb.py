@@ -36,3 +36,14 @@ for cfg in cfgs:
         if best is None or ms < best[0]: best = (ms, c["segments"] / c["gpuMs"] / 1e3)
     print(f"config {cfg}: {best[0]:8.3f} ms/frame  {best[1]:9.1f} Mrays/s   (segments/frame {c['segments']/frames:.3e}, setup {tb:.1f}s)")
     tr.close()
+
+if os.environ.get("RT_PHASES"):
+    for cfg in cfgs:
+        tr = api.create_tracer(0)
+        sc = pkg.scenes.get(cfg); mgr = sc.make_manager(tr, api); mgr.OnEnable(renderSeed=1)
+        tr.enable_stats(True); tr.reset_counters(); mgr.RenderFrames(1)
+        c = tr.counters(); ph = tr.phase_profile()
+        print(f"config {cfg} phase profile (1 frame, {c['segments']} segments):")
+        for k, (e, l) in ph.items():
+            if e: print(f"   {k:14s} wave-execs {e:12d}  lanes {l:13d}  util {l/(64*e):.3f}  execs/segment*64 {e*64/c['segments']:.2f}")
+        tr.close()
