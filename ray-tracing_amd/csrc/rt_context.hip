@@ -47,6 +47,7 @@ struct RtContext {
     DTriN* dNorms = nullptr;
     uint32_t* dBigLeaves = nullptr;
     int nSpheres = 0, nModels = 0, nTris = 0, nPairs = 0;
+    bool flatScene = false; /* every model root is a leaf: the FLAT kernel variant applies */
     int stackEntries = 1; /* deepest BVH of the scene = most entries a lane can push */
     bool haveScene = false;
     /* scene (host mirrors needed by rt_update_models) */
@@ -461,6 +462,9 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
     ctx->nTris = n_triangles;
     ctx->nPairs = (int)sb.pairs.size();
     ctx->stackEntries = maxHeight;
+    ctx->flatScene = true;
+    for (int i = 0; i < n_models; i++)
+        if (!(rootCodes[i] & RT_CODE_LEAF)) ctx->flatScene = false;
     ctx->hModels.assign(models, models + n_models);
     ctx->hRootCodes = rootCodes;
     ctx->haveScene = true;
@@ -587,10 +591,14 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
     int tiles = a.tilesX * a.tilesY;
     if (tiles == 0) return RT_OK;
     const size_t stackBytes = (size_t)ctx->stackEntries * RT_WAVE * sizeof(uint32_t);
-    if (ctx->stats)
-        hipLaunchKernelGGL(rtk::rt_trace_kernel<true>, dim3(tiles), dim3(RT_WAVE), stackBytes, ctx->stream, a);
-    else
-        hipLaunchKernelGGL(rtk::rt_trace_kernel<false>, dim3(tiles), dim3(RT_WAVE), stackBytes, ctx->stream, a);
+    /* kernel variant: FLAT when no model has a tree below its root (decided at upload) */
+    if (ctx->flatScene) {
+        if (ctx->stats) hipLaunchKernelGGL((rtk::rt_trace_kernel<true, true>), dim3(tiles), dim3(RT_WAVE), stackBytes, ctx->stream, a);
+        else hipLaunchKernelGGL((rtk::rt_trace_kernel<false, true>), dim3(tiles), dim3(RT_WAVE), stackBytes, ctx->stream, a);
+    } else {
+        if (ctx->stats) hipLaunchKernelGGL((rtk::rt_trace_kernel<true, false>), dim3(tiles), dim3(RT_WAVE), stackBytes, ctx->stream, a);
+        else hipLaunchKernelGGL((rtk::rt_trace_kernel<false, false>), dim3(tiles), dim3(RT_WAVE), stackBytes, ctx->stream, a);
+    }
     HIP_TRY(ctx, hipGetLastError());
     ctx->pixelFrames += (uint64_t)ctx->localRows * ctx->W * nFrames;
     return RT_OK;

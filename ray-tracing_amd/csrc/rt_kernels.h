@@ -224,7 +224,7 @@ struct Trav {
     bool cull;
 };
 
-template <bool STATS>
+template <bool STATS, bool FLAT>
 __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f3 rdir, SceneHit& h, Trav& t, Stats& st)
 {
     h.dst = RT_INF;
@@ -288,7 +288,7 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
     unsigned long long cand = 0;
     const RT_CAS DModel* cm = (const RT_CAS DModel*)a.models;
     const RT_CAS DPair* cp = (const RT_CAS DPair*)a.pairs;
-    const int nf = a.nModels < 64 ? a.nModels : 64;
+    const int nf = FLAT ? 0 : (a.nModels < 64 ? a.nModels : 64);
     for (int m = 0; m < nf; m++) {
         const RT_CAS DModel& M = cm[m];
         const uint32_t root = M.rootCode;
@@ -444,12 +444,51 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
     return finished;
 }
 
+/* Scenes in which every model's root is a leaf (quads, small meshes built with
+ * Quality.Disabled — BASELINE configs 1 and 2): there is no tree to walk, so the
+ * reference's nested form is already convergent.  Wave-uniform model loop, matrices in
+ * SGPRs, the root leaf's triangles tested in order; no stack, no suspension. */
+template <bool STATS>
+__device__ __forceinline__ void traverse_flat(const KArgs& a, rt_f3 rpos, rt_f3 rdir, SceneHit& h, Stats& st)
+{
+    const RT_CAS DModel* cm = (const RT_CAS DModel*)a.models;
+    const DTri* __restrict__ tris = a.tris;
+    for (int m = 0; m < a.nModels; m++) {
+        const RT_CAS DModel& M = cm[m];
+        rt_f3 lpos = rt_v3(M.w2l[0] * rpos.x + M.w2l[1] * rpos.y + M.w2l[2] * rpos.z + M.w2l[3] * 1.0f,
+                           M.w2l[4] * rpos.x + M.w2l[5] * rpos.y + M.w2l[6] * rpos.z + M.w2l[7] * 1.0f,
+                           M.w2l[8] * rpos.x + M.w2l[9] * rpos.y + M.w2l[10] * rpos.z + M.w2l[11] * 1.0f);
+        rt_f3 ldir = rt_v3(M.w2l[0] * rdir.x + M.w2l[1] * rdir.y + M.w2l[2] * rdir.z + M.w2l[3] * 0.0f,
+                           M.w2l[4] * rdir.x + M.w2l[5] * rdir.y + M.w2l[6] * rdir.z + M.w2l[7] * 0.0f,
+                           M.w2l[8] * rdir.x + M.w2l[9] * rdir.y + M.w2l[10] * rdir.z + M.w2l[11] * 0.0f);
+        const uint32_t code = M.rootCode;
+        uint32_t count = (code >> 24) & 0x7fu;
+        uint32_t start = code & RT_CODE_MAX_INLINE_START;
+        if (count == 0) {
+            count = a.bigLeaves[2 * start + 1];
+            start = a.bigLeaves[2 * start];
+        }
+        if (STATS) { st.leaf++; st.tri += count; }
+        const int first = M.triBase + (int)start;
+        const bool cull = M.cullBackface != 0;
+        for (uint32_t i = 0; i < count; i++) {
+            phase_mark<STATS>(st, PH_TRI);
+            const float before = h.dst;
+            tri_test(tris, first + (int)i, lpos, ldir, cull, h.dst, h.tri, h.u, h.v, h.det);
+            if (h.dst < before) {
+                h.obj = a.nSpheres + m;
+                h.backface = h.det < 0;
+            }
+        }
+    }
+}
+
 /* Run-to-completion form (debug hook). */
 template <bool STATS>
 __device__ __forceinline__ void intersect_scene(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, SceneHit& h, Stats& st)
 {
     Trav t;
-    begin_intersect<STATS>(a, rpos, rdir, h, t, st);
+    begin_intersect<STATS, false>(a, rpos, rdir, h, t, st);
     traverse<STATS, false>(a, rpos, rdir, stackBase, h, t, st);
 }
 
@@ -496,7 +535,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
  * LDS: the per-lane traversal stack, [level][lane], sized by the host to the deepest
  * BVH of the scene (dynamic shared memory).
  * ------------------------------------------------------------------------- */
-template <bool STATS>
+template <bool STATS, bool FLAT>
 __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kernel(const KArgs a)
 {
     extern __shared__ uint32_t s_stack[];
@@ -593,12 +632,13 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
             }
             if (pathActive) {
                 phase_mark<STATS>(st, PH_SPHERES);
-                begin_intersect<STATS>(a, rpos, rdir, h, t, st);
+                begin_intersect<STATS, FLAT>(a, rpos, rdir, h, t, st);
                 segments++;
                 inTrav = true;
+                if (FLAT) traverse_flat<STATS>(a, rpos, rdir, h, st);
             }
         }
-        if (inTrav && traverse<STATS, true>(a, rpos, rdir, stackBase, h, t, st)) {
+        if (inTrav && (FLAT || traverse<STATS, true>(a, rpos, rdir, stackBase, h, t, st))) {
             inTrav = false;
             /* the rest of one iteration of Trace's bounce loop — RC:488-538 */
             bool endPath = false;

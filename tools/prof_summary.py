@@ -18,11 +18,11 @@ for d in sorted(glob.glob(os.path.join(out, "trace", "**", "*.db"), recursive=Tr
         res.setdefault("dispatch", []).append(dict(zip(
             ["name", "vgpr", "agpr", "sgpr", "lds", "scratch", "grid", "wg", "n", "avg_ns", "min_ns", "max_ns"], r)))
 res["pmc"] = {}
-print("== PMC per dispatch of rt_trace_kernel<false> (avg over n dispatches; separate passes):")
+print("== PMC per dispatch of rt_trace_kernel<false,*> (avg over n dispatches; separate passes):")
 for d in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*.db"), recursive=True)):
     cur = sqlite3.connect(d).cursor()
     q = ("select counter_name, count(*), avg(v), min(v), max(v) from (select counter_name, dispatch_id, sum(value) as v "
-         "from counters_collection where kernel_name like '%rt_trace_kernel<false>%' group by counter_name, dispatch_id) group by counter_name")
+         "from counters_collection where kernel_name like '%rt_trace_kernel<false%' group by counter_name, dispatch_id) group by counter_name")
     for name, n, avg, mn, mx in cur.execute(q):
         print("   %-26s n=%3d avg=%.6g min=%.6g max=%.6g" % (name, n, avg, mn, mx))
         res["pmc"][name] = {"n": n, "avg": avg, "min": mn, "max": mx}
