@@ -1,0 +1,59 @@
+"""host/dotnet/RayTraceNative.cs cannot be compiled here (no .NET in the image); keep it honest by
+checking its struct declarations field-by-field against include/rt_abi.h, and its DllImports
+against the header's function list."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def c_structs():
+    text = open(os.path.join(ROOT, "include", "rt_abi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"typedef struct (\w+) \{(.*?)\} \1;", text, flags=re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            ctype, rest = decl.split(None, 1)
+            for item in rest.split(","):
+                item = item.strip()
+                am = re.match(r"(\w+)\[(\d+)\]", item)
+                fields.append((ctype, am.group(1), int(am.group(2))) if am else (ctype, item, 1))
+        out[m.group(1)] = fields
+    return out
+
+
+def cs_structs():
+    text = open(os.path.join(ROOT, "host", "dotnet", "RayTraceNative.cs")).read()
+    out = {}
+    for m in re.finditer(r"public struct (\w+)\s*\{(.*?)\n    \}", text, flags=re.S):
+        fields = []
+        for fm in re.finditer(r"(?:\[MarshalAs\(UnmanagedType\.ByValArray, SizeConst = (\d+)\)\]\s*)?public (\w+)(\[\])? (\w+);", m.group(2)):
+            fields.append((fm.group(2), fm.group(4), int(fm.group(1) or 1)))
+        out[m.group(1)] = fields
+    return out
+
+
+TYPE_MAP = {"float": "float", "int32_t": "int", "uint32_t": "uint", "uint64_t": "ulong", "double": "double",
+            "RtMaterial": "RtMaterial"}
+
+
+def test_csharp_structs_match_header():
+    c, cs = c_structs(), cs_structs()
+    for name in ("RtMaterial", "RtModel", "RtTriangle", "RtBVHNode", "RtSphere", "RtParams", "RtCounters"):
+        assert name in c and name in cs, name
+        assert len(c[name]) == len(cs[name]), name
+        for (ct, cn, cl), (st, sn, sl) in zip(c[name], cs[name]):
+            assert TYPE_MAP[ct] == st and cn == sn and cl == sl, (name, cn, sn)
+
+
+def test_csharp_imports_exist_in_header():
+    text = open(os.path.join(ROOT, "host", "dotnet", "RayTraceNative.cs")).read()
+    header = open(os.path.join(ROOT, "include", "rt_abi.h")).read()
+    imports = re.findall(r"extern \w+ (rt_\w+)\(", text)
+    assert len(imports) >= 20
+    for name in imports:
+        assert re.search(r"\b%s\s*\(" % name, header), name
