@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -61,6 +62,19 @@ struct RtContext {
 
     /* counters */
     unsigned long long* dCounters = nullptr;
+    unsigned long long* dTileQueue = nullptr; /* monotonic tile counter of the persistent kernel */
+    unsigned long long tileQueueNext = 0;     /* value the counter will have when the next launch starts */
+    uint32_t* dTileCost = nullptr;  /* per tile: longest pixel chain (segments per frame) seen so far */
+    uint32_t* dTileOrder = nullptr; /* queue position -> tile, longest chain first */
+    int orderTiles = 0;             /* tiles the two arrays are sized for; 0 = none */
+    bool orderValid = false;
+    long long framesSinceResize = 0;
+    bool lptEnabled = true;
+    int numCUs = 256;
+    int occPerCU[4] = {0, 0, 0, 0};
+    size_t occBytes[4] = {0, 0, 0, 0};
+    bool verbose = false;
+    int gridOverride = 0; /* test hook: force the persistent grid size */
     bool stats = false;
     uint64_t pixelFrames = 0;
     hipEvent_t evStart = nullptr, evStop = nullptr;
@@ -128,13 +142,23 @@ int rt_create(int device_id, RtContext** out)
     RtContext* ctx = new RtContext();
     ctx->device = device_id;
     HIP_TRY(ctx, hipSetDevice(device_id));
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(ctx, hipGetDeviceProperties(&prop, device_id));
+        ctx->numCUs = prop.multiProcessorCount;
+    }
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking));
     ctx->stream = ctx->ownStream;
     HIP_TRY(ctx, hipMalloc(&ctx->dCounters, sizeof(unsigned long long) * RT_COUNTER_SLOTS * RT_COUNTER_FIELDS));
     HIP_TRY(ctx, hipMemset(ctx->dCounters, 0, sizeof(unsigned long long) * RT_COUNTER_SLOTS * RT_COUNTER_FIELDS));
+    HIP_TRY(ctx, hipMalloc(&ctx->dTileQueue, sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemset(ctx->dTileQueue, 0, sizeof(unsigned long long)));
     HIP_TRY(ctx, hipEventCreate(&ctx->evStart));
     HIP_TRY(ctx, hipEventCreate(&ctx->evStop));
     memset(&ctx->params, 0, sizeof(ctx->params));
+    if (const char* g = getenv("RT_GRID")) ctx->gridOverride = atoi(g); /* tuning hook */
+    if (getenv("RT_VERBOSE")) ctx->verbose = true;
+    if (const char* l = getenv("RT_LPT")) ctx->lptEnabled = atoi(l) != 0;
     *out = ctx;
     return RT_OK;
 }
@@ -160,6 +184,9 @@ void rt_destroy(RtContext* ctx)
     hipFree(ctx->ownFrame);
     hipFree(ctx->ownAccum);
     hipFree(ctx->dCounters);
+    hipFree(ctx->dTileQueue);
+    hipFree(ctx->dTileCost);
+    hipFree(ctx->dTileOrder);
     if (ctx->evStart) hipEventDestroy(ctx->evStart);
     if (ctx->evStop) hipEventDestroy(ctx->evStop);
     if (ctx->ownStream) hipStreamDestroy(ctx->ownStream);
@@ -212,6 +239,7 @@ int rt_resize(RtContext* ctx, int width, int height)
         HIP_TRY(ctx, hipMemsetAsync(ctx->ownAccum, 0, bytes, ctx->stream));
     }
     ctx->boundFrame = ctx->boundAccum = nullptr;
+    ctx->orderTiles = 0; /* tile costs belong to the old geometry */
     return RT_OK;
 }
 
@@ -591,14 +619,49 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
     int tiles = a.tilesX * a.tilesY;
     if (tiles == 0) return RT_OK;
     const size_t stackBytes = (size_t)ctx->stackEntries * RT_WAVE * sizeof(uint32_t);
-    /* kernel variant: FLAT when no model has a tree below its root (decided at upload) */
-    if (ctx->flatScene) {
-        if (ctx->stats) hipLaunchKernelGGL((rtk::rt_trace_kernel<true, true>), dim3(tiles), dim3(RT_WAVE), stackBytes, ctx->stream, a);
-        else hipLaunchKernelGGL((rtk::rt_trace_kernel<false, true>), dim3(tiles), dim3(RT_WAVE), stackBytes, ctx->stream, a);
-    } else {
-        if (ctx->stats) hipLaunchKernelGGL((rtk::rt_trace_kernel<true, false>), dim3(tiles), dim3(RT_WAVE), stackBytes, ctx->stream, a);
-        else hipLaunchKernelGGL((rtk::rt_trace_kernel<false, false>), dim3(tiles), dim3(RT_WAVE), stackBytes, ctx->stream, a);
+    /* Persistent launch: as many single-wave workgroups as the chip keeps resident
+     * (occupancy query x CUs), never more than there are tiles.  The first `grid` tiles are
+     * taken by blockIdx, the rest through the atomic queue, which counts monotonically
+     * across launches: this launch's queue indices start at tileQueueBase. */
+    void (*kern)(const KArgs) = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_kernel<true, true> : rtk::rt_trace_kernel<false, true>)
+                                               : (ctx->stats ? rtk::rt_trace_kernel<true, false> : rtk::rt_trace_kernel<false, false>);
+    const int variant = (ctx->flatScene ? 2 : 0) + (ctx->stats ? 1 : 0);
+    if (ctx->occBytes[variant] != stackBytes + 1) { /* occupancy query cached per (variant, LDS bytes) */
+        int perCU = 0;
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, RT_WAVE, stackBytes));
+        ctx->occPerCU[variant] = perCU > 0 ? perCU : 1;
+        ctx->occBytes[variant] = stackBytes + 1;
     }
+    long long resident = (long long)ctx->occPerCU[variant] * ctx->numCUs;
+    int grid = (int)(resident < tiles ? resident : tiles);
+    if (ctx->gridOverride > 0) grid = ctx->gridOverride < tiles ? ctx->gridOverride : tiles;
+    /* longest-chain-first queue order, learnt from the frames already rendered at this size */
+    if (ctx->lptEnabled && ctx->orderTiles != tiles) {
+        hipFree(ctx->dTileCost); ctx->dTileCost = nullptr;
+        hipFree(ctx->dTileOrder); ctx->dTileOrder = nullptr;
+        HIP_TRY(ctx, hipMalloc(&ctx->dTileCost, sizeof(uint32_t) * tiles));
+        HIP_TRY(ctx, hipMalloc(&ctx->dTileOrder, sizeof(uint32_t) * tiles));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * tiles, ctx->stream));
+        ctx->orderTiles = tiles;
+        ctx->orderValid = false;
+        ctx->framesSinceResize = 0;
+    }
+    if (ctx->lptEnabled) {
+        const long long f = ctx->framesSinceResize;
+        if (f > 0 && (f & (f - 1)) == 0) { /* re-sort after frames 1, 2, 4, 8, ... */
+            hipLaunchKernelGGL(rtk::rt_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->dTileCost, ctx->dTileOrder, tiles);
+            HIP_TRY(ctx, hipGetLastError());
+            ctx->orderValid = true;
+        }
+        a.tileCost = ctx->dTileCost;
+        a.tileOrder = ctx->orderValid ? ctx->dTileOrder : nullptr;
+        ctx->framesSinceResize += nFrames;
+    }
+    if (ctx->verbose) fprintf(stderr, "[raytrace_hip] launch variant=%d tiles=%d grid=%d perCU=%d lds=%zu\n", variant, tiles, grid, ctx->occPerCU[variant], stackBytes);
+    a.tileQueue = ctx->dTileQueue;
+    a.tileQueueBase = ctx->tileQueueNext - (unsigned long long)grid;
+    ctx->tileQueueNext += (unsigned long long)(tiles - grid) + (unsigned long long)grid; /* each wave overshoots once */
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(RT_WAVE), stackBytes, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
     ctx->pixelFrames += (uint64_t)ctx->localRows * ctx->W * nFrames;
     return RT_OK;
@@ -735,7 +798,7 @@ int rt_get_counters(RtContext* ctx, RtCounters* out)
 /* Wave-level phase profile of the stats launches since rt_reset_counters:
  * out[2*p] = times a wave executed phase p, out[2*p+1] = lanes active in it
  * (p: 0 loop, 1 raygen, 2 spheres, 3 traverse call, 4 model setup, 5 inner step,
- *  6 triangle test, 7 shade hit, 8 sky). */
+ *  6 triangle test, 7 shade hit, 8 sky, 9 sphere roots, 10 glass branch, 11 pixel refill). */
 int rt_debug_phase_profile(RtContext* ctx, uint64_t* out, int n)
 {
     if (!ctx || !out || n < 2 * RT_N_PHASES) return fail(ctx, RT_ERR_INVALID_ARG, "rt_debug_phase_profile: need %d entries", 2 * RT_N_PHASES);

@@ -29,7 +29,7 @@
 #define RT_WAVE 64
 #define RT_STACK_DEPTH 34            /* >= RT_MAX_BVH_DEPTH + 2 */
 #define RT_COUNTER_SLOTS 1024        /* counters are spread over slots to avoid same-address atomics */
-#define RT_N_PHASES 9
+#define RT_N_PHASES 12
 #define RT_COUNTER_FIELDS (8 + 2 * RT_N_PHASES)
 
 /* node codes: bit31 = leaf.  leaf: [30:24] = triangle count (1..127), [23:0] = first
@@ -94,6 +94,13 @@ struct KArgs {
     float cam[16];
     /* counters: RT_COUNTER_SLOTS x RT_COUNTER_FIELDS u64 */
     unsigned long long* counters;
+    /* persistent waves: global tile queue (monotonic; this launch's tiles start at tileQueueBase) */
+    unsigned long long* tileQueue;
+    unsigned long long tileQueueBase;
+    /* longest-chain-first scheduling: queue position -> tile (null = identity), and the
+     * per-tile record of the longest pixel chain seen so far (segments in one frame) */
+    const uint32_t* tileOrder;
+    uint32_t* tileCost;
 };
 
 #endif

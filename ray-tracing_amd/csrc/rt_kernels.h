@@ -82,7 +82,7 @@ struct Stats {
      * and how many lanes were active in it — lane utilisation per phase = lanes / (64 * execs) */
     uint32_t phExec[RT_N_PHASES], phLanes[RT_N_PHASES];
 };
-enum { PH_LOOP = 0, PH_RAYGEN, PH_SPHERES, PH_TRAVERSE_CALL, PH_MODEL, PH_INNER, PH_TRI, PH_SHADE_HIT, PH_SKY };
+enum { PH_LOOP = 0, PH_RAYGEN, PH_SPHERES, PH_TRAVERSE_CALL, PH_MODEL, PH_INNER, PH_TRI, PH_SHADE_HIT, PH_SKY, PH_SPHERE_ROOTS, PH_GLASS, PH_REFILL };
 template <bool STATS>
 __device__ __forceinline__ void phase_mark(Stats& st, int ph)
 {
@@ -254,6 +254,7 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
             cand |= (disc >= 0 ? 1u : 0u) << k;
         }
         while (cand) {
+            phase_mark<STATS>(st, PH_SPHERE_ROOTS);
             const int k = __builtin_ctz(cand);
             cand &= cand - 1;
             const int s = base + k;
@@ -542,34 +543,31 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
     const int lane = threadIdx.x;
     uint32_t* stackBase = &s_stack[lane];
 
-    const int tile = blockIdx.x;
-    const int tx = tile % a.tilesX, ty = tile / a.tilesX;
-    const int x = tx * 8 + (lane & 7);
-    const int lrow = ty * 8 + (lane >> 3);
-    bool laneDone = !(x < (int)a.W && lrow < a.localRows);
-    /* cyclic strips: local strip ls is global strip ls*partCount + partIndex */
-    const int ls = lrow / a.stripRows;
-    const int y = (ls * a.partCount + a.partIndex) * a.stripRows + (lrow - ls * a.stripRows);
-
-    /* RCC:15 */
-    const float uvx = (float)(uint32_t)x / ((float)a.W - 1.0f);
-    const float uvy = (float)(uint32_t)y / ((float)a.H - 1.0f);
-    /* RC:547-558 */
+    /* wave-uniform camera constants — RC:547,557-558 */
     const rt_f3 camOrigin = rt_mul_point(a.cam, rt_v3(0.0f, 0.0f, 0.0f), 1.0f);
-    const uint32_t pixelCoordX = (uint32_t)(uvx * (float)a.W);
-    const uint32_t pixelCoordY = (uint32_t)(uvy * (float)a.H);
-    const uint32_t pixelIndex = pixelCoordY * a.W + pixelCoordX;
-    const rt_f3 fpl = rt_v3(uvx - 0.5f, uvy - 0.5f, 1.0f) * rt_v3(a.viewParams[0], a.viewParams[1], a.viewParams[2]);
-    const rt_f3 focusPoint = rt_mul_point(a.cam, fpl, 1.0f);
     const rt_f3 camRight = rt_v3(a.cam[0], a.cam[1], a.cam[2]);
     const rt_f3 camUp = rt_v3(a.cam[4], a.cam[5], a.cam[6]);
     const float numPixelsX = (float)a.W;
-
-    const size_t pixOff = ((size_t)lrow * a.W + (size_t)x) * 4;
-
-    int frame = a.frame0;
     const int frameEnd = a.frame0 + a.nFrames;
-    uint32_t rng = pixelIndex + (uint32_t)frame * 719393u + (uint32_t)a.seed; /* RC:552 */
+    const int nTiles = a.tilesX * a.tilesY;
+
+    /* Persistent wave: the wave starts on tile blockIdx.x and, whenever lanes run out of
+     * work (their pixel is finished), hands them the next unassigned pixels of its current
+     * "pool" tile, pulling a fresh 8x8 tile from a global atomic queue when the pool is
+     * used up.  Consecutive pool slots are neighbouring pixels, so the rays a wave holds stay
+     * spatially close, but no lane idles while its tile mates finish their longer paths. */
+    int poolTile = (int)blockIdx.x;
+    if (a.tileOrder && poolTile < nTiles) poolTile = (int)a.tileOrder[poolTile];
+    int poolPos = 0; /* next unassigned slot of the pool tile, 64 = exhausted */
+    if ((int)blockIdx.x >= nTiles || a.nFrames <= 0) poolPos = 64;
+    bool queueEmpty = (a.nFrames <= 0);
+
+    /* per-lane pixel state */
+    bool laneDone = true; /* no pixel assigned */
+    uint32_t pixelIndex = 0, pixLinear = 0, pixSegStart = 0;
+    rt_f3 focusPoint = rt_v3s(0.0f);
+    int frame = a.frame0;
+    uint32_t rng = 0;
     int sample = 0;
     rt_f3 totalIncoming = rt_v3s(0.0f);
 
@@ -583,10 +581,60 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
     t.cand = 0; t.rootStep = false; t.m = 0; t.cur = RT_CODE_NEXT_MODEL; t.sp = 0; t.lpos = t.ldir = t.linv = rt_v3s(0.0f); t.triBase = 0; t.cull = true;
     uint32_t segments = 0;
     Stats st = {};
-    if (a.nFrames <= 0) laneDone = true;
 
-    while (!laneDone) {
+    for (;;) {
+        /* ---- hand pixels to idle lanes (every lane of the wave is active here) */
+        unsigned long long idle = __ballot(laneDone);
+        while (idle) {
+            if (poolPos >= 64) {
+                if (queueEmpty) break;
+                int next = 0;
+                if (lane == 0) next = (int)(atomicAdd(a.tileQueue, 1ull) - a.tileQueueBase);
+                next = __builtin_amdgcn_readfirstlane(next);
+                if (next >= nTiles) { queueEmpty = true; break; }
+                poolTile = a.tileOrder ? (int)a.tileOrder[next] : next;
+                poolPos = 0;
+            }
+            const int rank = __popcll(idle & ((1ull << lane) - 1ull));
+            const int avail = 64 - poolPos;
+            if (laneDone && rank < avail) {
+                phase_mark<STATS>(st, PH_REFILL);
+                const int slot = poolPos + rank;
+                const int tx = poolTile % a.tilesX, ty = poolTile / a.tilesX;
+                const int x = tx * 8 + (slot & 7);
+                const int lrow = ty * 8 + (slot >> 3);
+                if (x < (int)a.W && lrow < a.localRows) {
+                    /* cyclic strips: local strip ls is global strip ls*partCount + partIndex */
+                    const int ls = lrow / a.stripRows;
+                    const int y = (ls * a.partCount + a.partIndex) * a.stripRows + (lrow - ls * a.stripRows);
+                    /* RCC:15 */
+                    const float uvx = (float)(uint32_t)x / ((float)a.W - 1.0f);
+                    const float uvy = (float)(uint32_t)y / ((float)a.H - 1.0f);
+                    /* RC:550-556 */
+                    const uint32_t pixelCoordX = (uint32_t)(uvx * (float)a.W);
+                    const uint32_t pixelCoordY = (uint32_t)(uvy * (float)a.H);
+                    pixelIndex = pixelCoordY * a.W + pixelCoordX;
+                    const rt_f3 fpl = rt_v3(uvx - 0.5f, uvy - 0.5f, 1.0f) * rt_v3(a.viewParams[0], a.viewParams[1], a.viewParams[2]);
+                    focusPoint = rt_mul_point(a.cam, fpl, 1.0f);
+                    pixLinear = (uint32_t)lrow * a.W + (uint32_t)x;
+                    pixSegStart = segments;
+                    frame = a.frame0;
+                    rng = pixelIndex + (uint32_t)frame * 719393u + (uint32_t)a.seed; /* RC:552 */
+                    sample = 0;
+                    totalIncoming = rt_v3s(0.0f);
+                    pathActive = false;
+                    inTrav = false;
+                    laneDone = false;
+                }
+            }
+            const int wanted = __popcll(idle);
+            poolPos += wanted < avail ? wanted : avail;
+            idle = __ballot(laneDone);
+        }
+        if (idle == ~0ull) break; /* nothing left anywhere */
+        if (!laneDone) {
         phase_mark<STATS>(st, PH_LOOP);
+        const size_t pixOff = (size_t)pixLinear * 4;
         if (!inTrav) {
             if (!pathActive) {
                 if (sample == a.spp) {
@@ -607,6 +655,10 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
                     frame++;
                     if (frame == frameEnd) {
                         laneDone = true;
+                        if (a.tileCost) { /* longest serial chain of this tile's pixels: next frame's queue order */
+                            const uint32_t prow = pixLinear / a.W, pcol = pixLinear - prow * a.W;
+                            atomicMax(a.tileCost + (prow >> 3) * (uint32_t)a.tilesX + (pcol >> 3), (segments - pixSegStart) / (uint32_t)a.nFrames);
+                        }
                     } else {
                         rng = pixelIndex + (uint32_t)frame * 719393u + (uint32_t)a.seed;
                         sample = 0;
@@ -663,6 +715,7 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
                 if (!isGlass) uSpec = rt_random_value(&rng); /* RC:521 */
                 const rt_f3 diffuseDir = rt_normalize(normal + rand_direction(&rng)); /* RC:509 / RC:525 */
                 if (isGlass) {
+                    phase_mark<STATS>(st, PH_GLASS);
                     if (h.backface) { /* RC:502 */
                         rt_f3 e = ((-h.dst) * rt_v3(mat.absorption[0], mat.absorption[1], mat.absorption[2])) * mat.absorptionStrength;
                         transmittance = transmittance * rt_v3(rt_exp(e.x), rt_exp(e.y), rt_exp(e.z));
@@ -701,6 +754,7 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
                 pathActive = false;
             }
         }
+        } /* !laneDone */
     }
 
     /* exact work counters: one set of atomics per wave, spread over slots */
@@ -769,6 +823,32 @@ __global__ void rt_debug_math_kernel(int op, const float* x, const float* y, flo
     case 7: r = rt_smoothstep(0.0f, y[i], x[i]); break;
     }
     out[i] = r;
+}
+
+/* Queue order for the next frame: tiles sorted by the longest pixel chain seen in them,
+ * longest first (counting sort, one workgroup).  A pixel's samples and bounces are one
+ * serial chain (quirk Q13), so a frame cannot end before its longest chain does; starting
+ * the long ones first keeps the end of the frame full of short work.  Pure scheduling:
+ * the image does not depend on it. */
+__global__ void __launch_bounds__(1024) rt_order_kernel(const uint32_t* cost, uint32_t* order, int nTiles)
+{
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t base[1024];
+    const int t = threadIdx.x;
+    hist[t] = 0;
+    __syncthreads();
+    for (int i = t; i < nTiles; i += 1024) atomicAdd(&hist[1023u - (cost[i] < 1023u ? cost[i] : 1023u)], 1u);
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int k = 0; k < 1024; k++) { base[k] = run; run += hist[k]; }
+    }
+    __syncthreads();
+    /* stable within a bucket is not needed; keep tile order roughly spatial by walking in index order per thread */
+    for (int i = t; i < nTiles; i += 1024) {
+        const uint32_t k = 1023u - (cost[i] < 1023u ? cost[i] : 1023u);
+        order[atomicAdd(&base[k], 1u)] = (uint32_t)i;
+    }
 }
 
 /* ResetAccumulated — RCC:26-32 */

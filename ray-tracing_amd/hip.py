@@ -103,7 +103,7 @@ class HipTracer(abi.Tracer):
         self._check(self.api.debug_intersect(self.h, o.ctypes.data, d.ctypes.data, len(o), out.ctypes.data))
         return out
 
-    PHASES = ["loop", "raygen", "spheres", "traverse_call", "model", "inner", "tri", "shade_hit", "sky"]
+    PHASES = ["loop", "raygen", "spheres", "traverse_call", "model", "inner", "tri", "shade_hit", "sky", "sphere_roots", "glass", "refill"]
 
     def phase_profile(self):
         out = np.zeros(2 * len(self.PHASES), dtype=np.uint64)
