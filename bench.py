@@ -14,7 +14,13 @@ Scene and render targets are resident in HBM before the timed region.
 counted exactly by the kernel.  For N > 1 the image is split into cyclic 8-row
 strips (one process per GPU, no data-path collective); the single RCCL gather
 of the tiles happens at readback, after the timed steps, and is reported
-separately (`gather_ms`).  Scaling is strong: the same 1920x1080 image for any N.
+separately (`gather_ms`).
+
+Scaling is WEAK by default: per-GPU work is fixed at 1920x1080 pixels — the image
+area grows with N at the same 16:9 view (N=4 is the north_star's 3840x2160), so
+every rank renders ~2.07 Mpixels of the same scene.  `--scaling strong` keeps the
+1920x1080 image for every N instead (a pixel's 8 samples x 9 segments are one
+serial chain, so a 1/8 image is bounded by that chain).
 
 Prints ONE JSON line on rank 0.
 """
@@ -65,6 +71,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, help="scene id (default 2 = the headline workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     args = ap.parse_args()
 
     import torch
@@ -88,10 +95,14 @@ def main():
     tracer = api.create_tracer(local_rank)
     scene = pkg.scenes.get(args.config)
     W, H = scene.width, scene.height
+    if world > 1 and args.scaling == "weak":
+        # same view, N x the pixels: both sides scaled by sqrt(N), kept multiples of 8
+        f = world ** 0.5
+        W, H = int(round(W * f / 8)) * 8, int(round(H * f / 8)) * 8
     tiled = None
     if world > 1:
         tiled = pkg.dist.TiledTracer(tracer, rank, world, device)
-    mgr = scene.make_manager(tracer, api)
+    mgr = scene.make_manager(tracer, api, W, H)
     mgr.OnEnable(renderSeed=1)  # resize + BVH build + upload + reset: everything resident in HBM
     if tiled:
         tiled.bind(W, H)
@@ -176,7 +187,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -184,11 +195,13 @@ def main():
                 "workload": f"{scene.name}: {W}x{H}, {scene.settings['numRaysPerPixel']} spp/frame, "
                             f"{scene.settings['maxBounceCount']} bounces, {n_spheres} spheres + {n_models} models "
                             f"({scene.unique_triangles()} triangles); BASELINE.json configs[{args.config - 1}]",
-                "parallelism": "single GPU" if world == 1 else f"image row-tiled, cyclic 8-row strips over {world} GPUs, RCCL gather at readback",
+                "parallelism": "single GPU" if world == 1 else f"{W}x{H} image row-tiled, cyclic 8-row strips over {world} GPUs "
+                               f"({args.scaling} scaling), RCCL gather at readback",
                 "renderSeed": 1, "first_timed_frame": first_frame,
             },
             "segments_per_step": total_segments / args.steps,
             "mpaths_per_s": W * H * scene.settings["numRaysPerPixel"] * args.steps / elapsed / 1e6,
+            "resolution": [W, H],
             "kernel_ms_per_step": kernel_ms_max / args.steps,
             "gather_ms": gather_ms,
             "parity": "bit-identical to oracle/ on tests/ (pytest -m gpu); max rel err 0",

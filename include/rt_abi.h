@@ -264,7 +264,8 @@ int rt_debug_math_eval(RtContext* ctx, int op, const float* x, const float* y, f
  * last rt_reset_counters: out[2p] = times a wave executed phase p, out[2p+1] = lanes
  * active in it (p: 0 loop, 1 camera ray, 2 spheres, 3 traverse call, 4 model setup,
  * 5 inner step, 6 triangle test, 7 shade hit, 8 sky, 9 sphere roots, 10 glass branch,
- * 11 pixel refill). n must be >= 24. */
+ * 11 pixel refill). n must be >= 24; if n >= 25, out[24] = number of times the conservative
+ * world-space root filter rejected a model the exact root step would have entered (must be 0). */
 int rt_debug_phase_profile(RtContext* ctx, uint64_t* out, int n);
 
 /* Library identification: returns "raytrace_hip gfx950 abi=<n>" */

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -47,6 +48,10 @@ struct RtContext {
     DTri* dTris = nullptr;
     DTriN* dNorms = nullptr;
     uint32_t* dBigLeaves = nullptr;
+    DFilter* dFilters = nullptr;
+    float filterMaxOrigin = 0.0f;
+    std::vector<RtBVHNode> hRootChildren;
+    std::vector<RtSphere> hSpheres; /* per model: the root's two children (for rt_update_models) */
     int nSpheres = 0, nModels = 0, nTris = 0, nPairs = 0;
     bool flatScene = false; /* every model root is a leaf: the FLAT kernel variant applies */
     int stackEntries = 1; /* deepest BVH of the scene = most entries a lane can push */
@@ -172,6 +177,7 @@ static void free_scene(RtContext* ctx)
     hipFree(ctx->dTris); ctx->dTris = nullptr;
     hipFree(ctx->dNorms); ctx->dNorms = nullptr;
     hipFree(ctx->dBigLeaves); ctx->dBigLeaves = nullptr;
+    hipFree(ctx->dFilters); ctx->dFilters = nullptr;
     ctx->haveScene = false;
 }
 
@@ -298,6 +304,114 @@ static void pack_model(const RtModel& m, uint32_t rootCode, DModel& d)
     d.rootCode = rootCode;
     d.triBase = m.triOffset;
     d.cullBackface = m.material.flag != RT_MATERIAL_GLASS; /* RC:355 */
+}
+
+/* World-space, inflated boxes of a model's two root children — the conservative root filter
+ * of begin_intersect.  Corners go through inverse(worldToLocal) in double precision; the
+ * inflation (1e-4 of the scene extent plus 1e-5 of the model's own coordinate range, mapped to
+ * world units) is two to three orders of magnitude above the fp32 rounding of the reference's
+ * local-space slab test.  A matrix that is not affine-invertible in a well-conditioned way
+ * disables the filter for that model. */
+static bool invert_affine(const float* m /* column-major 4x4 */, double inv[12] /* 3 rows x 4 */)
+{
+    double a[3][3], t[3];
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) a[r][c] = m[c * 4 + r];
+        t[r] = m[12 + r];
+    }
+    if (m[3] != 0.0f || m[7] != 0.0f || m[11] != 0.0f || m[15] != 1.0f) return false;
+    double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                 a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+    double scale = 0;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) scale = fmax(scale, fabs(a[r][c]));
+    if (!(fabs(det) > 1e-9 * scale * scale * scale) || !std::isfinite(det)) return false;
+    double id = 1.0 / det;
+    double b[3][3];
+    b[0][0] = (a[1][1] * a[2][2] - a[1][2] * a[2][1]) * id; b[0][1] = (a[0][2] * a[2][1] - a[0][1] * a[2][2]) * id; b[0][2] = (a[0][1] * a[1][2] - a[0][2] * a[1][1]) * id;
+    b[1][0] = (a[1][2] * a[2][0] - a[1][0] * a[2][2]) * id; b[1][1] = (a[0][0] * a[2][2] - a[0][2] * a[2][0]) * id; b[1][2] = (a[0][2] * a[1][0] - a[0][0] * a[1][2]) * id;
+    b[2][0] = (a[1][0] * a[2][1] - a[1][1] * a[2][0]) * id; b[2][1] = (a[0][1] * a[2][0] - a[0][0] * a[2][1]) * id; b[2][2] = (a[0][0] * a[1][1] - a[0][1] * a[1][0]) * id;
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) inv[r * 4 + c] = b[r][c];
+        inv[r * 4 + 3] = -(b[r][0] * t[0] + b[r][1] * t[1] + b[r][2] * t[2]);
+        for (int c = 0; c < 4; c++)
+            if (!std::isfinite(inv[r * 4 + c])) return false;
+    }
+    return true;
+}
+
+/* returns false if the model cannot be filtered; otherwise world boxes (not yet inflated) in wmin/wmax[2][3] */
+static bool world_boxes(const RtModel& m, const RtBVHNode children[2], double wmin[2][3], double wmax[2][3], double* localRange)
+{
+    double inv[12];
+    if (!invert_affine(m.worldToLocal, inv)) return false;
+    double range = 0, normS = 0;
+    for (int r = 0; r < 3; r++) normS = fmax(normS, fabs(inv[r * 4]) + fabs(inv[r * 4 + 1]) + fabs(inv[r * 4 + 2]));
+    for (int k = 0; k < 2; k++) {
+        for (int d = 0; d < 3; d++) {
+            if (!std::isfinite(children[k].boundsMin[d]) || !std::isfinite(children[k].boundsMax[d])) return false;
+            wmin[k][d] = INFINITY;
+            wmax[k][d] = -INFINITY;
+            range = fmax(range, fmax(fabs((double)children[k].boundsMin[d]), fabs((double)children[k].boundsMax[d])));
+        }
+        for (int corner = 0; corner < 8; corner++) {
+            double p[3];
+            for (int d = 0; d < 3; d++) p[d] = (corner >> d & 1) ? children[k].boundsMax[d] : children[k].boundsMin[d];
+            for (int r = 0; r < 3; r++) {
+                double w = inv[r * 4] * p[0] + inv[r * 4 + 1] * p[1] + inv[r * 4 + 2] * p[2] + inv[r * 4 + 3];
+                wmin[k][r] = fmin(wmin[k][r], w);
+                wmax[k][r] = fmax(wmax[k][r], w);
+            }
+        }
+    }
+    *localRange = range * normS;
+    return true;
+}
+
+static void make_filters(const RtModel* models, int n_models, const std::vector<uint32_t>& rootCodes, const std::vector<RtBVHNode>& rootChildren,
+                         const RtSphere* spheres, int n_spheres, std::vector<DFilter>& out, float* maxOrigin)
+{
+    out.assign(n_models, DFilter());
+    std::vector<double> lr(n_models, 0.0);
+    std::vector<char> ok(n_models, 0);
+    std::vector<double> bmin((size_t)n_models * 6), bmax((size_t)n_models * 6);
+    double extent = 0;
+    for (int i = 0; i < n_models; i++) {
+        DFilter& f = out[i];
+        memset(&f, 0, sizeof(f));
+        f.innerRoot = (rootCodes[i] & RT_CODE_LEAF) ? 0u : 1u;
+        f.always = 1;
+        if (!f.innerRoot) continue;
+        double wmin[2][3], wmax[2][3];
+        if (!world_boxes(models[i], &rootChildren[2 * (size_t)i], wmin, wmax, &lr[i])) continue;
+        ok[i] = 1;
+        for (int k = 0; k < 2; k++)
+            for (int d = 0; d < 3; d++) {
+                bmin[(size_t)i * 6 + k * 3 + d] = wmin[k][d];
+                bmax[(size_t)i * 6 + k * 3 + d] = wmax[k][d];
+                extent = fmax(extent, fmax(fabs(wmin[k][d]), fabs(wmax[k][d])));
+            }
+    }
+    for (int i = 0; i < n_spheres; i++)
+        for (int d = 0; d < 3; d++) extent = fmax(extent, fabs((double)spheres[i].centre[d]) + fabs((double)spheres[i].radius));
+    if (!std::isfinite(extent)) extent = 0;
+    for (int i = 0; i < n_models; i++) {
+        if (!ok[i]) continue;
+        DFilter& f = out[i];
+        const double margin = 1e-4 * extent + 1e-5 * lr[i] + 1e-30;
+        bool fin = true;
+        for (int k = 0; k < 2; k++)
+            for (int d = 0; d < 3; d++) {
+                float lo = nextafterf((float)(bmin[(size_t)i * 6 + k * 3 + d] - margin), -INFINITY);
+                float hi = nextafterf((float)(bmax[(size_t)i * 6 + k * 3 + d] + margin), INFINITY);
+                (k ? f.bMin : f.aMin)[d] = lo;
+                (k ? f.bMax : f.aMax)[d] = hi;
+                fin = fin && std::isfinite(lo) && std::isfinite(hi);
+            }
+        f.always = fin ? 0u : 1u;
+    }
+    /* rays starting farther than this from the origin have coarser fp32 spacing than the margin allows for */
+    *maxOrigin = (float)(8.0 * extent);
 }
 
 struct SceneBuilder {
@@ -428,6 +542,7 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
     sb.nTris = n_triangles;
     sb.pairOfFirstChild.assign((size_t)n_nodes + 1, -1);
     std::vector<uint32_t> rootCodes(n_models);
+    std::vector<RtBVHNode> rootChildren((size_t)n_models * 2);
     int maxHeight = 1;
     for (int i = 0; i < n_models; i++) {
         const RtModel& m = models[i];
@@ -441,6 +556,10 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
             return fail(ctx, RT_ERR_SCENE, "model %d: %s", i, sb.error.c_str());
         if (height > RT_MAX_BVH_DEPTH) return fail(ctx, RT_ERR_SCENE, "model %d: BVH depth %d > %d", i, height, RT_MAX_BVH_DEPTH);
         if (height > maxHeight) maxHeight = height;
+        if (!(rootCodes[i] & RT_CODE_LEAF)) {
+            rootChildren[2 * (size_t)i] = nodes[m.nodeOffset + root.startIndex];
+            rootChildren[2 * (size_t)i + 1] = nodes[m.nodeOffset + root.startIndex + 1];
+        }
     }
 
     /* ---- triangles: RC:190-192 are ray independent, pre-difference them (same fp32 ops) */
@@ -476,6 +595,10 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
         pack_material(models[i].material, mats[n_spheres + i]);
     }
 
+    std::vector<DFilter> filters;
+    float maxOrigin = 0;
+    make_filters(models, n_models, rootCodes, rootChildren, spheres, n_spheres, filters, &maxOrigin);
+
     free_scene(ctx);
     int rc;
     if ((rc = upload_vec(ctx, &ctx->dSpheres, sph.data(), sph.size()))) return rc;
@@ -485,6 +608,10 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
     if ((rc = upload_vec(ctx, &ctx->dTris, dtris.data(), dtris.size()))) return rc;
     if ((rc = upload_vec(ctx, &ctx->dNorms, dnorms.data(), dnorms.size()))) return rc;
     if ((rc = upload_vec(ctx, &ctx->dBigLeaves, sb.bigLeaves.data(), sb.bigLeaves.size()))) return rc;
+    if ((rc = upload_vec(ctx, &ctx->dFilters, filters.data(), filters.size()))) return rc;
+    ctx->filterMaxOrigin = maxOrigin;
+    ctx->hRootChildren = rootChildren;
+    ctx->hSpheres.assign(spheres, spheres + n_spheres);
     ctx->nSpheres = n_spheres;
     ctx->nModels = n_models;
     ctx->nTris = n_triangles;
@@ -517,6 +644,11 @@ int rt_update_models(RtContext* ctx, const RtModel* models, int n_models)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(ctx->dModels, dmodels.data(), sizeof(DModel) * n_models, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->dMaterials + ctx->nSpheres, mats.data(), sizeof(DMaterial) * n_models, hipMemcpyHostToDevice));
+    {
+        std::vector<DFilter> filters;
+        make_filters(models, n_models, ctx->hRootCodes, ctx->hRootChildren, ctx->hSpheres.data(), (int)ctx->hSpheres.size(), filters, &ctx->filterMaxOrigin);
+        HIP_TRY(ctx, hipMemcpy(ctx->dFilters, filters.data(), sizeof(DFilter) * n_models, hipMemcpyHostToDevice));
+    }
     ctx->hModels.assign(models, models + n_models);
     return RT_OK;
 }
@@ -538,6 +670,12 @@ int rt_update_spheres(RtContext* ctx, const RtSphere* spheres, int n_spheres)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(ctx->dSpheres, sph.data(), sph.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->dMaterials, mats.data(), sizeof(DMaterial) * n_spheres, hipMemcpyHostToDevice));
+    ctx->hSpheres.assign(spheres, spheres + n_spheres);
+    if (ctx->nModels) {
+        std::vector<DFilter> filters;
+        make_filters(ctx->hModels.data(), ctx->nModels, ctx->hRootCodes, ctx->hRootChildren, spheres, n_spheres, filters, &ctx->filterMaxOrigin);
+        HIP_TRY(ctx, hipMemcpy(ctx->dFilters, filters.data(), sizeof(DFilter) * ctx->nModels, hipMemcpyHostToDevice));
+    }
     return RT_OK;
 }
 
@@ -581,6 +719,8 @@ static void fill_args(RtContext* ctx, int frame0, int nFrames, KArgs& a)
     a.tris = ctx->dTris;
     a.norms = ctx->dNorms;
     a.bigLeaves = ctx->dBigLeaves;
+    a.filters = ctx->dFilters;
+    a.filterMaxOrigin = ctx->filterMaxOrigin;
     a.nSpheres = ctx->nSpheres;
     a.nModels = ctx->nModels;
     a.frameRender = ctx->boundFrame ? ctx->boundFrame : ctx->ownFrame;
@@ -809,6 +949,10 @@ int rt_debug_phase_profile(RtContext* ctx, uint64_t* out, int n)
     for (int f = 0; f < 2 * RT_N_PHASES; f++) {
         out[f] = 0;
         for (int s = 0; s < RT_COUNTER_SLOTS; s++) out[f] += h[(size_t)s * RT_COUNTER_FIELDS + 8 + f];
+    }
+    if (n > 2 * RT_N_PHASES) { /* audit of the conservative root filter: must be 0 */
+        out[2 * RT_N_PHASES] = 0;
+        for (int s = 0; s < RT_COUNTER_SLOTS; s++) out[2 * RT_N_PHASES] += h[(size_t)s * RT_COUNTER_FIELDS + 6];
     }
     return RT_OK;
 }

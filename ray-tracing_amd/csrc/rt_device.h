@@ -62,6 +62,16 @@ struct DModel {
     int32_t cullBackface; /* material.flag != GLASS (RC:355) */
     int32_t pad[5];
 };
+/* Conservative world-space stand-in for a model's root step (see begin_intersect): the
+ * root's two child boxes, transformed to world space and inflated; `always` = no filtering
+ * (leaf root, or a matrix that cannot be inverted robustly). 64 B, scalar-loaded. */
+struct DFilter {
+    float aMin[3], aMax[3];
+    float bMin[3], bMax[3];
+    uint32_t always;
+    uint32_t innerRoot;
+    uint32_t pad[2];
+};
 struct DMaterial {
     float diffuseCol[4], emissionCol[4], specularCol[4], absorption[4];
     float absorptionStrength, emissionStrength, smoothness, specularProbability;
@@ -79,6 +89,8 @@ struct KArgs {
     const DTri* tris;
     const DTriN* norms;
     const uint32_t* bigLeaves;   /* pairs of (start, count) */
+    const DFilter* filters;      /* one per model */
+    float filterMaxOrigin;       /* ray origins farther than this from 0 skip the filter */
     int32_t nSpheres, nModels;
     /* render targets: rows owned by this context, packed */
     float* frameRender;

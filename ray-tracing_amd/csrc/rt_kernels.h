@@ -77,7 +77,7 @@ struct SceneHit {
 };
 
 struct Stats {
-    uint32_t inner, leaf, tri, sphere, model;
+    uint32_t inner, leaf, tri, sphere, model, filterViolations;
     /* wave-level phase profile (stats launches only): how often the wave executed a phase
      * and how many lanes were active in it — lane utilisation per phase = lanes / (64 * execs) */
     uint32_t phExec[RT_N_PHASES], phLanes[RT_N_PHASES];
@@ -279,38 +279,53 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
     }
     if (STATS) st.sphere += (uint32_t)a.nSpheres;
 
-    /* Root filter, in lockstep over the models (wave-uniform loop, matrices and the root's
-     * child boxes in SGPRs): transform the ray (RC:351-353) and run the root's two box tests
-     * (RC:269-270).  A model whose root children are both missed — or both farther than the
-     * closest sphere hit, result.dst only ever shrinks — contributes nothing in the reference
-     * (nothing is pushed, RC:280-281), so only the others are handed to the per-lane traversal,
-     * which redoes the same arithmetic for them in model order.  The reference's root step is
-     * still counted for every model. */
+    /* Root filter, in lockstep over the models (wave-uniform loop, boxes in SGPRs).
+     * In the reference every model costs a ray two matrix-vector products, three divides
+     * and the root's two box tests (RC:351-353, 269-270) before most rays find they miss it.
+     * A model whose root children are both missed contributes nothing (nothing is pushed,
+     * RC:280-281).  Here that decision is taken CONSERVATIVELY in world space: the root's two
+     * child boxes were transformed to world space and inflated on upload (rt_context.hip,
+     * make_filter), so one slab test per box with the world ray — no transform, one
+     * reciprocal per segment — never rejects a model the reference would descend into; the
+     * models that pass get the reference's exact arithmetic in the per-lane traversal, in
+     * model order.  The filter only saves work: results and counters do not depend on it
+     * (the stats build counts any exact-keep / filter-reject disagreement: must be 0). */
     unsigned long long cand = 0;
-    const RT_CAS DModel* cm = (const RT_CAS DModel*)a.models;
-    const RT_CAS DPair* cp = (const RT_CAS DPair*)a.pairs;
+    const RT_CAS DFilter* cf = (const RT_CAS DFilter*)a.filters;
     const int nf = FLAT ? 0 : (a.nModels < 64 ? a.nModels : 64);
-    for (int m = 0; m < nf; m++) {
-        const RT_CAS DModel& M = cm[m];
-        const uint32_t root = M.rootCode;
-        bool keep = true;
-        if (!(root & RT_CODE_LEAF)) {
-            rt_f3 lpos = rt_v3(M.w2l[0] * rpos.x + M.w2l[1] * rpos.y + M.w2l[2] * rpos.z + M.w2l[3] * 1.0f,
-                               M.w2l[4] * rpos.x + M.w2l[5] * rpos.y + M.w2l[6] * rpos.z + M.w2l[7] * 1.0f,
-                               M.w2l[8] * rpos.x + M.w2l[9] * rpos.y + M.w2l[10] * rpos.z + M.w2l[11] * 1.0f);
-            rt_f3 ldir = rt_v3(M.w2l[0] * rdir.x + M.w2l[1] * rdir.y + M.w2l[2] * rdir.z + M.w2l[3] * 0.0f,
-                               M.w2l[4] * rdir.x + M.w2l[5] * rdir.y + M.w2l[6] * rdir.z + M.w2l[7] * 0.0f,
-                               M.w2l[8] * rdir.x + M.w2l[9] * rdir.y + M.w2l[10] * rdir.z + M.w2l[11] * 0.0f);
-            rt_f3 linv = rt_v3(1 / ldir.x, 1 / ldir.y, 1 / ldir.z);
-            const RT_CAS DPair& P = cp[root];
-            float aMin[3] = {P.aMin[0], P.aMin[1], P.aMin[2]}, aMax[3] = {P.aMax[0], P.aMax[1], P.aMax[2]};
-            float bMin[3] = {P.bMin[0], P.bMin[1], P.bMin[2]}, bMax[3] = {P.bMax[0], P.bMax[1], P.bMax[2]};
-            float dstA = box_dst(lpos, linv, aMin, aMax);
-            float dstB = box_dst(lpos, linv, bMin, bMax);
-            keep = (dstA < h.dst) || (dstB < h.dst);
-            if (STATS) st.inner++;
+    if (nf > 0) {
+        const rt_f3 winv = rt_v3(__builtin_amdgcn_rcpf(rdir.x), __builtin_amdgcn_rcpf(rdir.y), __builtin_amdgcn_rcpf(rdir.z));
+        const bool farOrigin = !(rt_abs(rpos.x) <= a.filterMaxOrigin && rt_abs(rpos.y) <= a.filterMaxOrigin && rt_abs(rpos.z) <= a.filterMaxOrigin);
+        for (int m = 0; m < nf; m++) {
+            const RT_CAS DFilter& F = cf[m];
+            bool keep = true;
+            if (!F.always) {
+                float aMin[3] = {F.aMin[0], F.aMin[1], F.aMin[2]}, aMax[3] = {F.aMax[0], F.aMax[1], F.aMax[2]};
+                float bMin[3] = {F.bMin[0], F.bMin[1], F.bMin[2]}, bMax[3] = {F.bMax[0], F.bMax[1], F.bMax[2]};
+                float dA = box_dst(rpos, winv, aMin, aMax);
+                float dB = box_dst(rpos, winv, bMin, bMax);
+                /* box_dst returns +inf for a miss; '<=' (not '<') on the distance keeps it conservative */
+                keep = farOrigin || (dA < RT_INF && dA <= h.dst) || (dB < RT_INF && dB <= h.dst);
+            }
+            if (STATS) {
+                st.inner += F.innerRoot;
+                if (F.innerRoot && !keep) { /* audit the conservative filter against the exact root step */
+                    const RT_CAS DModel& M = ((const RT_CAS DModel*)a.models)[m];
+                    rt_f3 lpos = rt_v3(M.w2l[0] * rpos.x + M.w2l[1] * rpos.y + M.w2l[2] * rpos.z + M.w2l[3] * 1.0f,
+                                       M.w2l[4] * rpos.x + M.w2l[5] * rpos.y + M.w2l[6] * rpos.z + M.w2l[7] * 1.0f,
+                                       M.w2l[8] * rpos.x + M.w2l[9] * rpos.y + M.w2l[10] * rpos.z + M.w2l[11] * 1.0f);
+                    rt_f3 ldir = rt_v3(M.w2l[0] * rdir.x + M.w2l[1] * rdir.y + M.w2l[2] * rdir.z + M.w2l[3] * 0.0f,
+                                       M.w2l[4] * rdir.x + M.w2l[5] * rdir.y + M.w2l[6] * rdir.z + M.w2l[7] * 0.0f,
+                                       M.w2l[8] * rdir.x + M.w2l[9] * rdir.y + M.w2l[10] * rdir.z + M.w2l[11] * 0.0f);
+                    rt_f3 linv = rt_v3(1 / ldir.x, 1 / ldir.y, 1 / ldir.z);
+                    const RT_CAS DPair& P = ((const RT_CAS DPair*)a.pairs)[M.rootCode];
+                    float pa0[3] = {P.aMin[0], P.aMin[1], P.aMin[2]}, pa1[3] = {P.aMax[0], P.aMax[1], P.aMax[2]};
+                    float pb0[3] = {P.bMin[0], P.bMin[1], P.bMin[2]}, pb1[3] = {P.bMax[0], P.bMax[1], P.bMax[2]};
+                    if (box_dst(lpos, linv, pa0, pa1) < h.dst || box_dst(lpos, linv, pb0, pb1) < h.dst) st.filterViolations++;
+                }
+            }
+            cand |= (keep ? 1ull : 0ull) << m;
         }
-        cand |= (keep ? 1ull : 0ull) << m;
     }
     if (STATS) st.model += (uint32_t)a.nModels;
 
@@ -769,6 +784,10 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
             atomicAdd(slot + 3, (unsigned long long)tr);
             atomicAdd(slot + 4, (unsigned long long)sp);
             atomicAdd(slot + 5, (unsigned long long)md);
+        }
+        {
+            uint32_t fv = wave_sum(st.filterViolations);
+            if (lane == 0 && fv) atomicAdd(slot + 6, (unsigned long long)fv);
         }
         for (int p = 0; p < RT_N_PHASES; p++) {
             uint32_t e = wave_sum(st.phExec[p]), l = wave_sum(st.phLanes[p]);

@@ -106,9 +106,11 @@ class HipTracer(abi.Tracer):
     PHASES = ["loop", "raygen", "spheres", "traverse_call", "model", "inner", "tri", "shade_hit", "sky", "sphere_roots", "glass", "refill"]
 
     def phase_profile(self):
-        out = np.zeros(2 * len(self.PHASES), dtype=np.uint64)
+        out = np.zeros(2 * len(self.PHASES) + 1, dtype=np.uint64)
         self._check(self.api.debug_phase_profile(self.h, out.ctypes.data, len(out)))
-        return {p: (int(out[2 * i]), int(out[2 * i + 1])) for i, p in enumerate(self.PHASES)}
+        prof = {p: (int(out[2 * i]), int(out[2 * i + 1])) for i, p in enumerate(self.PHASES)}
+        prof["filter_violations"] = (int(out[-1]), 0)
+        return prof
 
     def debug_math_eval(self, op, x, y=None):
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -280,6 +280,57 @@ def test_config3_full_size_strip_sample(pkg, api, orc):
         assert bits_equal(gpu[s * 8: s * 8 + 8], cpu[s * 8: s * 8 + 8]), s
 
 
+# ------------------------------------------------------------------ scheduling must not change results
+@pytest.mark.parametrize("grid", ["1", "3", "1000000"])
+def test_persistent_grid_size_does_not_change_results(pkg, api, orc, grid, monkeypatch):
+    """One wave pulling every tile through the queue, three waves, or one wave per tile: same bits."""
+    monkeypatch.setenv("RT_GRID", grid)
+    a, b, ca, cb = pair(pkg, api, orc, 3, 72, 40, 2)
+    assert bits_equal(a, b)
+    assert [ca[k] for k in KEYS] == [cb[k] for k in KEYS]
+
+
+def test_tile_order_learning_does_not_change_results(pkg, api, orc):
+    """9 frames: the longest-chain-first queue order is re-learnt after frames 1, 2, 4 and 8."""
+    a, b, ca, cb = pair(pkg, api, orc, 2, 96, 54, 9)
+    assert bits_equal(a, b) and ca["segments"] == cb["segments"]
+    a, b, _, _ = pair(pkg, api, orc, 3, 64, 36, 9, stats=False)
+    assert bits_equal(a, b)
+
+
+def test_conservative_root_filter_never_rejects_what_the_reference_enters(pkg, api):
+    """The stats build audits the world-space root filter against the exact local-space root step
+    for every (ray, model) it rejects; also with rotated / non-uniformly scaled / tiny models."""
+    def audit(cfg, w, h, frames, kw=None, tweak=None):
+        tr = api.create_tracer(0)
+        tr.enable_stats(True)
+        render(pkg, api, tr, cfg, w, h, frames, scene_kw=kw, tweak=tweak)
+        prof = tr.phase_profile()
+        tr.close()
+        assert prof["model"][1] > 0
+        return prof["filter_violations"][0]
+    assert audit(3, 320, 180, 2) == 0
+    assert audit(4, 160, 90, 1, {"subdivisions": 4}) == 0
+    assert audit(5, 160, 90, 1, {"subdivisions": 3}) == 0
+
+    def nasty(mgr):
+        T = pkg.Transform
+        mgr.models[7].transform = T((-0.9, 0.7, 0.4), (33, 47, 71), (0.02, 1.7, 0.4))     # sliver, rotated
+        mgr.models[8].transform = T((1.2, 0.3, -0.5), (80, 10, 200), (1e-3, 1e-3, 1e-3))  # tiny
+        mgr.models[2].transform = T((-2.75, 2, -1), (0, 0, 1e-3), (0.15, 4.3, 12))        # almost axis-aligned wall
+    assert audit(3, 320, 180, 2, tweak=nasty) == 0
+
+
+def test_far_camera_disables_filter_safely(pkg, api, orc):
+    """Ray origins far outside the scene extent (coarse fp32 spacing) bypass the filter; results still exact."""
+    def far(mgr):
+        mgr.camera.transform = pkg.Transform(position=(0, 1.9, -500.0))
+        mgr.camera.fieldOfView = 1.0
+    a, b, ca, cb = pair(pkg, api, orc, 3, 64, 36, 1, tweak=far)
+    assert bits_equal(a, b)
+    assert [ca[k] for k in KEYS] == [cb[k] for k in KEYS]
+
+
 # ------------------------------------------------------------------ error behaviour of the ABI
 def test_abi_errors(pkg, api):
     a = pkg.abi

@@ -45,5 +45,6 @@ if os.environ.get("RT_PHASES"):
         c = tr.counters(); ph = tr.phase_profile()
         print(f"config {cfg} phase profile (1 frame, {c['segments']} segments):")
         for k, (e, l) in ph.items():
+            if k == 'filter_violations': print('   filter_violations', e); continue
             if e: print(f"   {k:14s} wave-execs {e:12d}  lanes {l:13d}  util {l/(64*e):.3f}  execs/segment*64 {e*64/c['segments']:.2f}")
         tr.close()
