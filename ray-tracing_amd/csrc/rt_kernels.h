@@ -34,8 +34,8 @@
 /* waves per SIMD the register allocator must leave room for (launch_bounds 2nd argument) */
 /* traverse() is left once active <= entered * NUM/DEN lanes are still traversing */
 #ifndef RT_SUSPEND_NUM
-#define RT_SUSPEND_NUM 1
-#define RT_SUSPEND_DEN 4
+#define RT_SUSPEND_NUM 3
+#define RT_SUSPEND_DEN 8
 #endif
 #ifndef RT_MIN_WAVES_PER_SIMD
 #define RT_MIN_WAVES_PER_SIMD 5
@@ -351,7 +351,7 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
  * h.dst is result.dst carried from model to model (rayLength = result.dst, RC:359).
  *
  * Returns true when this lane has visited every model.  With SUSPEND the wave leaves
- * the loop as soon as at most half of the lanes that entered are still traversing;
+ * the loop as soon as at most RT_SUSPEND_NUM/RT_SUSPEND_DEN of the lanes that entered are still traversing;
  * the stragglers keep their state in `t`/`h`/LDS and resume at the next call. */
 template <bool STATS, bool SUSPEND>
 __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, SceneHit& h, Trav& t, Stats& st)
