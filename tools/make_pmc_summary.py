@@ -1,0 +1,22 @@
+"""Build profiles/pmc_summary.json (read by bench.py for roofline.traffic) from tools/prof.sh outputs:
+usage: python tools/make_pmc_summary.py <key>=<gpurun_out/prof_dir> ..."""
+import json, os, sys
+out = {}
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_summary.json")
+if os.path.exists(path):
+    out = json.load(open(path))
+for arg in sys.argv[1:]:
+    key, d = arg.split("=")
+    s = json.load(open(os.path.join(d, "summary.json")))
+    p = s["pmc"]
+    rd = p["FETCH_SIZE"]["avg"] * 1024 * 2      # KiB -> B, x2: gfx950 FETCH_SIZE under-count (MI355X_MICROARCH.md §HBM)
+    wr = p["WRITE_SIZE"]["avg"] * 1024
+    out[key] = {
+        "hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
+        "l2_hit_rate": p["TCC_HIT_sum"]["avg"] / (p["TCC_HIT_sum"]["avg"] + p["TCC_MISS_sum"]["avg"]),
+        "valu_insts": p["SQ_INSTS_VALU"]["avg"], "valu_lane_utilisation": p["SQ_THREAD_CYCLES_VALU"]["avg"] / (p["SQ_ACTIVE_INST_VALU"]["avg"] * 64),
+        "kernel_avg_us_rocprof": [k["avg_us"] for k in s["kernel_stats"] if "rt_trace_kernel<false" in k["name"]][0],
+        "source": d,
+    }
+json.dump(out, open(path, "w"), indent=1)
+print(json.dumps(out, indent=1))
