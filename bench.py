@@ -84,15 +84,23 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # Test hooks (single-GPU boxes): RT_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 and
+    # RT_BENCH_BACKEND=gloo replaces RCCL, so the N>1 code path can be exercised without N GPUs.
+    dev_index = 0 if os.environ.get("RT_BENCH_ONE_DEVICE") else local_rank
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    comm_device = device if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     pkg = graft.load_package()
     api = pkg.load_library()
-    tracer = api.create_tracer(local_rank)
+    tracer = api.create_tracer(dev_index)
     scene = pkg.scenes.get(args.config)
     W, H = scene.width, scene.height
     if world > 1 and args.scaling == "weak":
@@ -150,16 +158,16 @@ def main():
     if tiled:
         barrier()
         g0 = time.perf_counter()
-        full = tiled.gather_accumulated(H)
+        full = tiled.gather_accumulated(H, comm_device=comm_device)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
         del full
 
     if world > 1:
-        t = torch.tensor([elapsed, float(timed["gpuMs"])], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, float(timed["gpuMs"])], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms_max = t[0].item(), t[1].item()
-        s = torch.tensor([segments, pkg.abi.algorithmic_bytes(stats, n_models, n_spheres)], dtype=torch.float64, device=device)
+        s = torch.tensor([segments, pkg.abi.algorithmic_bytes(stats, n_models, n_spheres)], dtype=torch.float64, device=comm_device)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         total_segments, total_bytes = s[0].item(), s[1].item()
     else:

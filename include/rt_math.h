@@ -53,10 +53,17 @@ RT_HD float rt_sign(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
 RT_HD float rt_saturate(float x) { return rt_min(rt_max(x, 0.0f), 1.0f); }
 /* HLSL lerp(a,b,t) as compilers lower it: a + (b-a)*t */
 RT_HD float rt_lerp(float a, float b, float t) { return a + (b - a) * t; }
-/* HLSL smoothstep(a,b,x) */
-RT_HD float rt_smoothstep(float a, float b, float x)
+/* HLSL '/': GPUs have no IEEE divide in shaders — a/b executes as a * rcp(b).  The strict
+ * form used here keeps that shape with a correctly rounded reciprocal, so a reciprocal of
+ * a wave-uniform or repeated denominator is computed once. */
+RT_HD float rt_rcp(float x) { return 1.0f / x; }
+RT_HD float rt_div(float a, float b) { return a * rt_rcp(b); }
+/* HLSL smoothstep(a,b,x) = saturate((x-a)/(b-a)) then Hermite; every call site of the shader
+ * passes literal edges (RC:175-176), for which the compiler folds 1/(b-a) into a constant:
+ * inv_range is that constant (correctly rounded). */
+RT_HD float rt_smoothstep(float a, float inv_range, float x)
 {
-    float t = rt_saturate((x - a) / (b - a));
+    float t = rt_saturate((x - a) * inv_range);
     return t * t * (3.0f - 2.0f * t);
 }
 
@@ -224,7 +231,8 @@ RT_HD rt_f3 operator-(rt_f3 a, rt_f3 b) { return rt_v3(a.x - b.x, a.y - b.y, a.z
 RT_HD rt_f3 operator*(rt_f3 a, rt_f3 b) { return rt_v3(a.x * b.x, a.y * b.y, a.z * b.z); }
 RT_HD rt_f3 operator*(rt_f3 a, float s) { return rt_v3(a.x * s, a.y * s, a.z * s); }
 RT_HD rt_f3 operator*(float s, rt_f3 a) { return rt_v3(s * a.x, s * a.y, s * a.z); }
-RT_HD rt_f3 operator/(rt_f3 a, float s) { return rt_v3(a.x / s, a.y / s, a.z / s); }
+/* float3 / scalar: one reciprocal, three multiplies (see rt_div) */
+RT_HD rt_f3 operator/(rt_f3 a, float s) { float r = rt_rcp(s); return rt_v3(a.x * r, a.y * r, a.z * r); }
 RT_HD rt_f3 operator-(rt_f3 a) { return rt_v3(-a.x, -a.y, -a.z); }
 /* HLSL dot(): left-to-right sum of products */
 RT_HD float rt_dot(rt_f3 a, rt_f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
@@ -232,9 +240,24 @@ RT_HD rt_f3 rt_cross(rt_f3 a, rt_f3 b)
 {
     return rt_v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-/* HLSL rsqrt(): the hardware instruction is an approximation; the strict
- * definition here is 1/sqrt(x) with both operations correctly rounded. */
-RT_HD float rt_rsqrt(float x) { return 1.0f / rt_sqrt(x); }
+/* HLSL rsqrt(): an approximation instruction on GPUs (1-2 ulp).  The strict definition
+ * here is a fixed algorithm in IEEE mul/sub only: the classic exponent-halving seed and
+ * three Newton steps y <- y*(1.5 - 0.5*x*y*y) (relative error 3.4e-2 -> 1.7e-3 -> 4.6e-6 ->
+ * fp32 rounding, < 1.5 ulp; tests/test_math.py).  Half the cost of sqrt followed by a divide.
+ * rsqrt(+-0) = +-inf, rsqrt(x<0) = NaN, rsqrt(inf) = 0, subnormals are pre-scaled by 2^48. */
+RT_HD float rt_rsqrt(float x)
+{
+    if (!(x > 0.0f)) return (x == 0.0f) ? rt_u2f((rt_f2u(x) & 0x80000000u) | 0x7f800000u) : rt_u2f(0x7fc00000u);
+    if (x == RT_INF) return 0.0f;
+    float scale = 1.0f;
+    if (x < 1.17549435e-38f) { x *= 281474976710656.0f; scale = 16777216.0f; } /* 2^48, 2^24 */
+    float y = rt_u2f(0x5f375a86u - (rt_f2u(x) >> 1));
+    const float h = 0.5f * x;
+    y = y * (1.5f - h * y * y);
+    y = y * (1.5f - h * y * y);
+    y = y + y * (0.5f - h * y * y); /* last step in residual form: its rounding error stays below 1 ulp */
+    return y * scale;
+}
 /* HLSL normalize(): DXC lowers it to v * rsqrt(dot(v,v)) — followed here with
  * the strict rsqrt above (one sqrt, one divide, three multiplies).  A zero
  * vector gives NaNs (0 * inf), like the shader. */

@@ -112,10 +112,10 @@ static float3 GetEnvironmentLight(const RtParams& P, float3 dir)
     const float3 SkyColourHorizon = rt_v3(1, 1, 1);
     const float3 SkyColourZenith = rt_v3(0.08f, 0.37f, 0.73f);
 
-    float skyGradientT = rt_pow(rt_smoothstep(0, 0.4f, dir.y), 0.35f);
-    float groundToSkyT = rt_smoothstep(-0.01f, 0, dir.y);
+    float skyGradientT = rt_pow(rt_smoothstep(0, 1.0f / 0.4f, dir.y), 0.35f);
+    float groundToSkyT = rt_smoothstep(-0.01f, 1.0f / 0.01f, dir.y);
     float3 skyGradient = rt_lerp3(SkyColourHorizon, SkyColourZenith, skyGradientT);
-    float s = 1000 * 1 / P.sunFocus; /* RC:178: (1000*1)/SunFocus */
+    float s = rt_div(1000 * 1, P.sunFocus); /* RC:178: (1000*1)/SunFocus */
     float sun = rt_pow(rt_max(0, rt_dot(dir, f3(P.dirToSun))), s) * P.sunIntensity;
     float gate = (groundToSkyT >= 1) ? 1.0f : 0.0f;
     float3 composite = rt_lerp3(GroundColour, skyGradient, groundToSkyT) + sun * f3(P.sunColour) * gate;
@@ -132,7 +132,7 @@ static TriangleHitInfo RayTriangle(const Ray& ray, const RtTriangle& tri, bool c
     float3 vertRayOffset = ray.pos - posA;
     float3 rayOffsetPerp = rt_cross(vertRayOffset, ray.dir);
     float determinant = -rt_dot(ray.dir, triFaceVector);
-    float invDet = 1 / determinant;
+    float invDet = rt_rcp(determinant);
 
     float dst = rt_dot(vertRayOffset, triFaceVector) * invDet;
     float u = rt_dot(edgeAC, rayOffsetPerp) * invDet;
@@ -238,8 +238,8 @@ static ModelHitInfo RaySphere(float3 rayPos, float3 rayDir, float3 sphereCentre,
 
     if (discriminant >= 0) {
         float s = rt_sqrt(discriminant);
-        float dstNear = rt_max(0, (-b - s) / (2 * a));
-        float dstFar = (-b + s) / (2 * a);
+        float dstNear = rt_max(0, rt_div(-b - s, 2 * a));
+        float dstFar = rt_div(-b + s, 2 * a);
 
         if (dstFar >= 0) {
             hitInfo.didHit = true;
@@ -285,7 +285,7 @@ static ModelHitInfo CalculateRayCollision(const Scene& sc, const Ray& worldRay, 
         /* RC:351-353 */
         localRay.pos = rt_mul_point(model.worldToLocal, worldRay.pos, 1);
         localRay.dir = rt_mul_point(model.worldToLocal, worldRay.dir, 0);
-        localRay.invDir = rt_v3(1 / localRay.dir.x, 1 / localRay.dir.y, 1 / localRay.dir.z);
+        localRay.invDir = rt_v3(rt_rcp(localRay.dir.x), rt_rcp(localRay.dir.y), rt_rcp(localRay.dir.z));
 
         bool cullBackface = model.material.flag != RT_MATERIAL_GLASS;
         if (forceDontCullBack) cullBackface = false;
@@ -306,7 +306,7 @@ static ModelHitInfo CalculateRayCollision(const Scene& sc, const Ray& worldRay, 
 /* ------------------------------------------------------------ RC:383-437 */
 static float CalculateReflectance(float3 inDir, float3 normal, float iorA, float iorB)
 {
-    float refractRatio = iorA / iorB;
+    float refractRatio = rt_div(iorA, iorB);
     float cosAngleIn = -rt_dot(inDir, normal);
     float sinSqrAngleOfRefraction = refractRatio * refractRatio * (1 - cosAngleIn * cosAngleIn);
     if (sinSqrAngleOfRefraction >= 1) return 1;
@@ -317,16 +317,16 @@ static float CalculateReflectance(float3 inDir, float3 normal, float iorA, float
 
     if (rt_min(denominatorPerpendicular, denominatorParallel) < 1E-8f) return 1;
 
-    float rPerpendicular = (iorA * cosAngleIn - iorB * cosAngleOfRefraction) / denominatorPerpendicular;
+    float rPerpendicular = rt_div(iorA * cosAngleIn - iorB * cosAngleOfRefraction, denominatorPerpendicular);
     rPerpendicular *= rPerpendicular;
-    float rParallel = (iorB * cosAngleIn - iorA * cosAngleOfRefraction) / denominatorParallel;
+    float rParallel = rt_div(iorB * cosAngleIn - iorA * cosAngleOfRefraction, denominatorParallel);
     rParallel *= rParallel;
 
-    return (rPerpendicular + rParallel) / 2;
+    return rt_div(rPerpendicular + rParallel, 2);
 }
 static float3 Refract(float3 inDir, float3 normal, float iorA, float iorB)
 {
-    float refractRatio = iorA / iorB;
+    float refractRatio = rt_div(iorA, iorB);
     float cosAngleIn = -rt_dot(inDir, normal);
     float sinSqrAngleOfRefraction = refractRatio * refractRatio * (1 - cosAngleIn * cosAngleIn);
     if (sinSqrAngleOfRefraction > 1) return rt_v3s(0);
@@ -349,7 +349,7 @@ static LightResponse CalculateReflectionAndRefraction(float3 inDir, float3 norma
 }
 
 /* ------------------------------------------------------------ RC:376-379, 450-466 */
-static float mod2(float x, float y) { return x - y * rt_floor(x / y); }
+static float mod2(float x, float y) { return x - y * rt_floor(rt_div(x, y)); }
 
 static float3 GetMaterialColour(const RtMaterial& mat, float3 pos, float3 normal, bool isSpecularBounce)
 {
@@ -375,7 +375,7 @@ static Ray CreateRay(float3 origin, float3 dir, float3 transmittance, int bounce
     Ray ray;
     ray.pos = origin;
     ray.dir = dir;
-    ray.invDir = rt_v3(1 / dir.x, 1 / dir.y, 1 / dir.z);
+    ray.invDir = rt_v3(rt_rcp(dir.x), rt_rcp(dir.y), rt_rcp(dir.z));
     ray.transmittance = transmittance;
     ray.bounceCount = bounceIndex;
     return ray;
@@ -432,7 +432,7 @@ static float3 Trace(const Scene& sc, const RtParams& P, Ray initialRay, uint32_t
 
         float p = rt_max(ray.transmittance.x, rt_max(ray.transmittance.y, ray.transmittance.z));
         if (rt_random_value(rngState) >= p) break;
-        ray.transmittance = ray.transmittance * (1 / p);
+        ray.transmittance = ray.transmittance * rt_rcp(p);
     }
     return totalLight;
 }
@@ -459,11 +459,11 @@ static float3 RayTracePixel(const Scene& sc, const RtParams& P, float2 uv, uint3
 
     for (int rayIndex = 0; rayIndex < P.numRaysPerPixel; rayIndex++) {
         float2 dj = RandomPointInCircle(&rngState);
-        float2 defocusJitter = {dj.x * P.defocusStrength / (float)numPixelsX, dj.y * P.defocusStrength / (float)numPixelsX};
+        float2 defocusJitter = {rt_div(dj.x * P.defocusStrength, (float)numPixelsX), rt_div(dj.y * P.defocusStrength, (float)numPixelsX)};
         float3 rayOrigin = camOrigin + camRight * defocusJitter.x + camUp * defocusJitter.y;
 
         float2 jj = RandomPointInCircle(&rngState);
-        float2 jitter = {jj.x * P.divergeStrength / (float)numPixelsX, jj.y * P.divergeStrength / (float)numPixelsX};
+        float2 jitter = {rt_div(jj.x * P.divergeStrength, (float)numPixelsX), rt_div(jj.y * P.divergeStrength, (float)numPixelsX)};
         float3 jitteredFocusPoint = focusPoint + camRight * jitter.x + camUp * jitter.y;
         float3 rayDir = rt_normalize(jitteredFocusPoint - rayOrigin);
 
@@ -765,7 +765,7 @@ int oracle_render_frame(OracleContext* ctx)
             if (y >= r1) break;
             for (int x = 0; x < W; x++) {
                 /* RCC:13-15 */
-                float2 uv = {(float)(uint32_t)x / ((float)(uint32_t)W - 1.0f), (float)(uint32_t)y / ((float)(uint32_t)H - 1.0f)};
+                float2 uv = {rt_div((float)(uint32_t)x, (float)(uint32_t)W - 1.0f), rt_div((float)(uint32_t)y, (float)(uint32_t)H - 1.0f)};
                 float3 pixelCol = RayTracePixel(ctx->scene, P, uv, (uint32_t)W, (uint32_t)H, st);
                 size_t o = ((size_t)y * W + x) * 4;
                 /* RCC:18 */
@@ -996,7 +996,7 @@ void oracle_ray_collision_bruteforce(OracleContext* ctx, const float pos[3], con
         Ray lr;
         lr.pos = rt_mul_point(model.worldToLocal, f3(pos), 1);
         lr.dir = rt_mul_point(model.worldToLocal, f3(dir), 0);
-        lr.invDir = rt_v3(1 / lr.dir.x, 1 / lr.dir.y, 1 / lr.dir.z);
+        lr.invDir = rt_v3(rt_rcp(lr.dir.x), rt_rcp(lr.dir.y), rt_rcp(lr.dir.z));
         bool cull = model.material.flag != RT_MATERIAL_GLASS;
         /* all triangles of the model's mesh = the triangle range covered by its BVH */
         int lo = INT32_MAX, hi = -1;
@@ -1021,7 +1021,7 @@ void oracle_trace_pixel(OracleContext* ctx, int x, int y, int frame, float out[3
     RtParams P = ctx->params;
     P.frame = frame;
     Counters c;
-    float2 uv = {(float)(uint32_t)x / ((float)(uint32_t)ctx->W - 1.0f), (float)(uint32_t)y / ((float)(uint32_t)ctx->H - 1.0f)};
+    float2 uv = {rt_div((float)(uint32_t)x, (float)(uint32_t)ctx->W - 1.0f), rt_div((float)(uint32_t)y, (float)(uint32_t)ctx->H - 1.0f)};
     float3 col = RayTracePixel(ctx->scene, P, uv, (uint32_t)ctx->W, (uint32_t)ctx->H, c);
     out[0] = col.x; out[1] = col.y; out[2] = col.z;
 }
@@ -1036,8 +1036,10 @@ void oracle_math_eval(int op, const float* x, const float* y, float* out, int n)
         case 3: out[i] = rt_cos(x[i]); break;
         case 4: out[i] = rt_sqrt(x[i]); break;
         case 5: out[i] = rt_pow(x[i], y[i]); break;
-        case 6: out[i] = x[i] / y[i]; break;
+        case 6: out[i] = rt_div(x[i], y[i]); break;
         case 7: out[i] = rt_smoothstep(0.0f, y[i], x[i]); break;
+        case 8: out[i] = rt_rsqrt(x[i]); break;
+        case 9: out[i] = rt_rcp(x[i]); break;
         default: out[i] = 0; break;
         }
     }

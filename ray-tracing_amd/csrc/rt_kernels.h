@@ -121,10 +121,10 @@ __device__ __forceinline__ rt_f2 rand_circle(uint32_t* state)
 /* GetEnvironmentLight — RC:167-183 (UseSky checked by the caller) */
 __device__ __forceinline__ rt_f3 environment_light(const KArgs& a, rt_f3 dir)
 {
-    float skyGradientT = rt_pow(rt_smoothstep(0.0f, 0.4f, dir.y), 0.35f);
-    float groundToSkyT = rt_smoothstep(-0.01f, 0.0f, dir.y);
+    float skyGradientT = rt_pow(rt_smoothstep(0.0f, 1.0f / 0.4f, dir.y), 0.35f);
+    float groundToSkyT = rt_smoothstep(-0.01f, 1.0f / 0.01f, dir.y);
     rt_f3 skyGradient = rt_lerp3(rt_v3(1, 1, 1), rt_v3(0.08f, 0.37f, 0.73f), skyGradientT);
-    float s = 1000 * 1 / a.sunFocus;
+    float s = rt_div(1000 * 1, a.sunFocus);
     rt_f3 toSun = rt_v3(a.dirToSun[0], a.dirToSun[1], a.dirToSun[2]);
     float sun = rt_pow(rt_max(0.0f, rt_dot(dir, toSun)), s) * a.sunIntensity;
     float gate = (groundToSkyT >= 1.0f) ? 1.0f : 0.0f;
@@ -135,7 +135,7 @@ __device__ __forceinline__ rt_f3 environment_light(const KArgs& a, rt_f3 dir)
 /* CalculateReflectance — RC:383-405 */
 __device__ __forceinline__ float reflectance(rt_f3 inDir, rt_f3 normal, float iorA, float iorB)
 {
-    float refractRatio = iorA / iorB;
+    float refractRatio = rt_div(iorA, iorB);
     float cosAngleIn = -rt_dot(inDir, normal);
     float sinSqr = refractRatio * refractRatio * (1 - cosAngleIn * cosAngleIn);
     if (sinSqr >= 1) return 1.0f;
@@ -143,16 +143,16 @@ __device__ __forceinline__ float reflectance(rt_f3 inDir, rt_f3 normal, float io
     float denomPerp = iorA * cosAngleIn + iorB * cosRefr;
     float denomPar = iorA * cosAngleIn + iorB * cosRefr; /* RC:392 repeats RC:391 */
     if (rt_min(denomPerp, denomPar) < 1E-8f) return 1.0f;
-    float rPerp = (iorA * cosAngleIn - iorB * cosRefr) / denomPerp;
+    float rPerp = rt_div(iorA * cosAngleIn - iorB * cosRefr, denomPerp);
     rPerp *= rPerp;
-    float rPar = (iorB * cosAngleIn - iorA * cosRefr) / denomPar;
+    float rPar = rt_div(iorB * cosAngleIn - iorA * cosRefr, denomPar);
     rPar *= rPar;
-    return (rPerp + rPar) / 2;
+    return rt_div(rPerp + rPar, 2);
 }
 /* Refract — RC:408-417 */
 __device__ __forceinline__ rt_f3 refract_dir(rt_f3 inDir, rt_f3 normal, float iorA, float iorB)
 {
-    float refractRatio = iorA / iorB;
+    float refractRatio = rt_div(iorA, iorB);
     float cosAngleIn = -rt_dot(inDir, normal);
     float sinSqr = refractRatio * refractRatio * (1 - cosAngleIn * cosAngleIn);
     if (sinSqr > 1) return rt_v3s(0.0f);
@@ -160,7 +160,7 @@ __device__ __forceinline__ rt_f3 refract_dir(rt_f3 inDir, rt_f3 normal, float io
 }
 
 /* GetMaterialColour — RC:450-466 with mod2 RC:376-379 */
-__device__ __forceinline__ float mod2f(float x, float y) { return x - y * rt_floor(x / y); }
+__device__ __forceinline__ float mod2f(float x, float y) { return x - y * rt_floor(rt_div(x, y)); }
 __device__ __forceinline__ rt_f3 material_colour(const DMaterial& mat, rt_f3 pos, rt_f3 normal, bool isSpecular)
 {
     rt_f3 col = rt_v3(mat.diffuseCol[0], mat.diffuseCol[1], mat.diffuseCol[2]);
@@ -191,7 +191,7 @@ __device__ __forceinline__ void tri_test(const DTri* __restrict__ tris, int triI
     rt_f3 vertRayOffset = pos - A;
     rt_f3 rayOffsetPerp = rt_cross(vertRayOffset, dir);
     float determinant = -rt_dot(dir, face);
-    float invDet = 1 / determinant;
+    float invDet = rt_rcp(determinant);
     float dst = rt_dot(vertRayOffset, face) * invDet;
     float u = rt_dot(edgeAC, rayOffsetPerp) * invDet;
     float v = -rt_dot(edgeAB, rayOffsetPerp) * invDet;
@@ -264,8 +264,9 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
             float qc = rt_dot(off, off) - sp.w;
             float disc = qb * qb - 4 * qa * qc;
             float sq = rt_sqrt(disc);
-            float dstNear = rt_max(0.0f, (-qb - sq) / (2 * qa));
-            float dstFar = (-qb + sq) / (2 * qa);
+            const float inv2a = rt_rcp(2 * qa); /* both roots share the reciprocal (rt_div) */
+            float dstNear = rt_max(0.0f, (-qb - sq) * inv2a);
+            float dstFar = (-qb + sq) * inv2a;
             if (dstFar >= 0) {
                 bool inside = dstNear == 0;
                 float d = inside ? dstFar : dstNear;
@@ -317,7 +318,7 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
                     rt_f3 ldir = rt_v3(M.w2l[0] * rdir.x + M.w2l[1] * rdir.y + M.w2l[2] * rdir.z + M.w2l[3] * 0.0f,
                                        M.w2l[4] * rdir.x + M.w2l[5] * rdir.y + M.w2l[6] * rdir.z + M.w2l[7] * 0.0f,
                                        M.w2l[8] * rdir.x + M.w2l[9] * rdir.y + M.w2l[10] * rdir.z + M.w2l[11] * 0.0f);
-                    rt_f3 linv = rt_v3(1 / ldir.x, 1 / ldir.y, 1 / ldir.z);
+                    rt_f3 linv = rt_v3(rt_rcp(ldir.x), rt_rcp(ldir.y), rt_rcp(ldir.z));
                     const RT_CAS DPair& P = ((const RT_CAS DPair*)a.pairs)[M.rootCode];
                     float pa0[3] = {P.aMin[0], P.aMin[1], P.aMin[2]}, pa1[3] = {P.aMax[0], P.aMax[1], P.aMax[2]};
                     float pb0[3] = {P.bMin[0], P.bMin[1], P.bMin[2]}, pb1[3] = {P.bMax[0], P.bMax[1], P.bMax[2]};
@@ -399,7 +400,7 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
                 t.cull = __float_as_uint(tail.z) != 0;
                 t.sp = 0;
                 /* invDir (RC:353) is only read by box tests: a mesh whose root is a leaf has none */
-                if (!(t.cur & RT_CODE_LEAF)) t.linv = rt_v3(1 / t.ldir.x, 1 / t.ldir.y, 1 / t.ldir.z);
+                if (!(t.cur & RT_CODE_LEAF)) t.linv = rt_v3(rt_rcp(t.ldir.x), rt_rcp(t.ldir.y), rt_rcp(t.ldir.z));
             }
         } else if (nB >= nC) {
             if (atInner) { /* ---- B: one inner node, RC:262-282 */
@@ -562,7 +563,7 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
     const rt_f3 camOrigin = rt_mul_point(a.cam, rt_v3(0.0f, 0.0f, 0.0f), 1.0f);
     const rt_f3 camRight = rt_v3(a.cam[0], a.cam[1], a.cam[2]);
     const rt_f3 camUp = rt_v3(a.cam[4], a.cam[5], a.cam[6]);
-    const float numPixelsX = (float)a.W;
+    const float invNumPixelsX = rt_rcp((float)a.W); /* x / numPixels.x == x * rcp (rt_div), wave-uniform */
     const int frameEnd = a.frame0 + a.nFrames;
     const int nTiles = a.tilesX * a.tilesY;
 
@@ -623,8 +624,8 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
                     const int ls = lrow / a.stripRows;
                     const int y = (ls * a.partCount + a.partIndex) * a.stripRows + (lrow - ls * a.stripRows);
                     /* RCC:15 */
-                    const float uvx = (float)(uint32_t)x / ((float)a.W - 1.0f);
-                    const float uvy = (float)(uint32_t)y / ((float)a.H - 1.0f);
+                    const float uvx = rt_div((float)(uint32_t)x, (float)a.W - 1.0f);
+                    const float uvy = rt_div((float)(uint32_t)y, (float)a.H - 1.0f);
                     /* RC:550-556 */
                     const uint32_t pixelCoordX = (uint32_t)(uvx * (float)a.W);
                     const uint32_t pixelCoordY = (uint32_t)(uvy * (float)a.H);
@@ -684,9 +685,9 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
                     /* RC:565-576: next camera ray of this pixel */
                     phase_mark<STATS>(st, PH_RAYGEN);
                     rt_f2 dj = rand_circle(&rng);
-                    rt_f3 rayOrigin = camOrigin + camRight * (dj.x * a.defocus / numPixelsX) + camUp * (dj.y * a.defocus / numPixelsX);
+                    rt_f3 rayOrigin = camOrigin + camRight * (dj.x * a.defocus * invNumPixelsX) + camUp * (dj.y * a.defocus * invNumPixelsX);
                     rt_f2 jj = rand_circle(&rng);
-                    rt_f3 jfp = focusPoint + camRight * (jj.x * a.diverge / numPixelsX) + camUp * (jj.y * a.diverge / numPixelsX);
+                    rt_f3 jfp = focusPoint + camRight * (jj.x * a.diverge * invNumPixelsX) + camUp * (jj.y * a.diverge * invNumPixelsX);
                     rpos = rayOrigin;
                     rdir = rt_normalize(jfp - rayOrigin);
                     transmittance = rt_v3s(1.0f);
@@ -759,7 +760,7 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
                 if (rt_random_value(&rng) >= p) {
                     endPath = true;
                 } else {
-                    transmittance = transmittance * (1 / p);
+                    transmittance = transmittance * rt_rcp(p);
                     bounce++;
                     if (bounce > a.maxBounce) endPath = true; /* RC:485: i <= MaxBounceCount */
                 }
@@ -838,7 +839,9 @@ __global__ void rt_debug_math_kernel(int op, const float* x, const float* y, flo
     case 3: r = rt_cos(x[i]); break;
     case 4: r = rt_sqrt(x[i]); break;
     case 5: r = rt_pow(x[i], y[i]); break;
-    case 6: r = x[i] / y[i]; break;
+    case 6: r = rt_div(x[i], y[i]); break;
+    case 8: r = rt_rsqrt(x[i]); break;
+    case 9: r = rt_rcp(x[i]); break;
     case 7: r = rt_smoothstep(0.0f, y[i], x[i]); break;
     }
     out[i] = r;

@@ -77,6 +77,9 @@ class TiledTracer:
         torch.cuda.synchronize(self.device)
         self.tracer.bind_render_targets(self.frame_t.data_ptr(), self.accum_t.data_ptr())
 
-    def gather_accumulated(self, height, dst=0):
+    def gather_accumulated(self, height, dst=0, comm_device=None):
+        """One collective: the accumulation tiles of all ranks -> full image on `dst`.
+        comm_device: where the collective runs (default: the tiles' own device, i.e. RCCL)."""
         self.tracer.synchronize()
-        return gather_image(self.accum_t, self.rank, self.world, height, dst)
+        local = self.accum_t if comm_device is None or comm_device == self.accum_t.device else self.accum_t.to(comm_device)
+        return gather_image(local, self.rank, self.world, height, dst)

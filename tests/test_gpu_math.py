@@ -17,17 +17,19 @@ SPECIAL = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, 1e-40,
                     2.0 ** -32, 1 - 2.0 ** -24, 0.5, 6.2831855, 88.7, -103.9, 87.3], dtype=np.float32)
 
 
-@pytest.mark.parametrize("op", ["log", "exp", "sin", "cos", "sqrt"])
+@pytest.mark.parametrize("op", ["log", "exp", "sin", "cos", "sqrt", "rsqrt", "rcp"])
 def test_unary_bits(api, orc, op):
     rng = np.random.default_rng(OPS[op])
     tr = api.create_tracer(0)
-    rngs = {"log": (0, 4), "exp": (-104, 89), "sin": (-7, 7), "cos": (-7, 7), "sqrt": (0, 1e6)}[op]
+    rngs = {"log": (0, 4), "exp": (-104, 89), "sin": (-7, 7), "cos": (-7, 7), "sqrt": (0, 1e6), "rsqrt": (0, 1e6), "rcp": (-1e4, 1e4)}[op]
     x = np.concatenate([sweep(rng, *rngs), SPECIAL, (rng.integers(0, 2 ** 32, 100000, dtype=np.uint64) / 4294967296.0).astype(np.float32),
                         rng.integers(0, 2 ** 32, 200000, dtype=np.uint64).astype(np.uint32).view(np.float32)])
     got = tr.debug_math_eval(OPS[op], x)
     want = ev(orc, op, x)
     tr.close()
-    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), op
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan]), op
 
 
 @pytest.mark.parametrize("op", ["pow", "div", "smoothstep"])

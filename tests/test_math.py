@@ -4,7 +4,7 @@ oracle library); tests/test_gpu_math.py checks the device evaluates the same bit
 import numpy as np
 import pytest
 
-OPS = {"log": 0, "exp": 1, "sin": 2, "cos": 3, "sqrt": 4, "pow": 5, "div": 6, "smoothstep": 7}
+OPS = {"log": 0, "exp": 1, "sin": 2, "cos": 3, "sqrt": 4, "pow": 5, "div": 6, "smoothstep": 7, "rsqrt": 8, "rcp": 9}
 
 
 def ev(orc, op, x, y=None):
@@ -84,17 +84,38 @@ def test_pow_matches_exp_log_and_hlsl_edges(orc):
     assert r[0] == 0.0 and r[1] == 1.0 and abs(r[2] - 0.25) < 1e-7 and r[3] == 0.0
 
 
-def test_div_sqrt_correctly_rounded(orc):
+def test_rcp_sqrt_correctly_rounded_and_div_is_mul_by_rcp(orc):
     rng = np.random.default_rng(6)
     a = rng.uniform(-1e3, 1e3, 200000).astype(np.float32)
     b = rng.uniform(1e-3, 1e3, 200000).astype(np.float32)
-    assert np.array_equal(ev(orc, "div", a, b), (a.astype(np.float64) / b.astype(np.float64)).astype(np.float32))
+    rcp = (1.0 / b.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(ev(orc, "rcp", b), rcp)
+    # HLSL '/' as GPUs execute it: a * rcp(b), each step correctly rounded (<= 1.5 ulp overall)
+    assert np.array_equal(ev(orc, "div", a, b), (a.astype(np.float64) * rcp.astype(np.float64)).astype(np.float32))
+    assert ulp_err(ev(orc, "div", a, b), a.astype(np.float64) / b.astype(np.float64)).max() <= 1.5
     assert np.array_equal(ev(orc, "sqrt", np.abs(a)), np.sqrt(np.abs(a).astype(np.float64)).astype(np.float32))
+
+
+def test_rsqrt_newton_accuracy_and_specials(orc):
+    rng = np.random.default_rng(8)
+    x = np.concatenate([rng.uniform(1e-6, 1e6, 300000), np.exp(rng.uniform(-85, 85, 200000)),
+                        [1.0, 4.0, 0.25, 1e-40, 1.2e-38, 3e38]]).astype(np.float32)
+    got = ev(orc, "rsqrt", x)
+    want = 1.0 / np.sqrt(x.astype(np.float64))
+    assert ulp_err(got, want).max() < 1.5, ulp_err(got, want).max()
+    r = ev(orc, "rsqrt", [0.0, -0.0, np.inf, -1.0, np.nan])
+    assert r[0] == np.inf and r[1] == -np.inf and r[2] == 0.0 and np.isnan(r[3]) and np.isnan(r[4])
+    # normalised vectors come out at unit length within a few ulp
+    v = rng.normal(size=(100000, 3)).astype(np.float32)
+    d = (v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1] + v[:, 2] * v[:, 2]).astype(np.float32)
+    n = v * ev(orc, "rsqrt", d)[:, None]
+    assert np.max(np.abs(np.linalg.norm(n.astype(np.float64), axis=1) - 1)) < 5e-7
 
 
 def test_smoothstep(orc):
     x = np.array([-1, 0, 0.1, 0.2, 0.4, 1, np.nan], dtype=np.float32)
-    e = np.full_like(x, 0.4)
-    r = ev(orc, "smoothstep", x, e)
+    inv = np.full_like(x, np.float32(1.0) / np.float32(0.4))   # the folded constant 1/(b-a)
+    r = ev(orc, "smoothstep", x, inv)
+    assert inv[0] == np.float32(2.5)
     assert r[0] == 0 and r[1] == 0 and r[4] == 1 and r[5] == 1 and abs(r[3] - 0.5) < 1e-6
     assert r[6] == 0  # saturate(NaN) = 0 (HLSL)
