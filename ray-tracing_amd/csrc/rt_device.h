@@ -29,6 +29,7 @@
 #define RT_WAVE 64
 #define RT_STACK_DEPTH 34            /* >= RT_MAX_BVH_DEPTH + 2 */
 #define RT_COUNTER_SLOTS 1024        /* counters are spread over slots to avoid same-address atomics */
+#define RT_PIXEL_FIELDS 11
 #define RT_N_PHASES 12
 #define RT_COUNTER_FIELDS (8 + 2 * RT_N_PHASES)
 
@@ -99,6 +100,7 @@ struct KArgs {
     int32_t localRows;
     int32_t stripRows, partIndex, partCount;
     int32_t tilesX, tilesY;
+    int32_t stackEntries;        /* LDS: [stackEntries][64] traversal stack, then [RT_PIXEL_FIELDS][64] pixel bookkeeping */
     /* uniforms (RtParams) */
     int32_t maxBounce, spp, frame0, nFrames, seed, useSky, accumulate;
     float defocus, diverge, sunFocus, sunIntensity;

@@ -580,12 +580,15 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
 
     /* per-lane pixel state */
     bool laneDone = true; /* no pixel assigned */
-    uint32_t pixelIndex = 0, pixLinear = 0, pixSegStart = 0;
-    rt_f3 focusPoint = rt_v3s(0.0f);
-    int frame = a.frame0;
+    /* Pixel bookkeeping that is only touched when a path starts or ends lives in LDS next to the
+     * traversal stack ([field][lane], conflict free), not in VGPRs: it would otherwise be carried
+     * through — and spilled around — the traversal and shading code. */
+    uint32_t* const pxu = &s_stack[(size_t)a.stackEntries * RT_WAVE + lane];
+    float* const pxf = reinterpret_cast<float*>(pxu);
+    enum { PX_INDEX = 0, PX_LINEAR, PX_SEGSTART, PX_FRAME, PX_SAMPLE, PX_FPX, PX_FPY, PX_FPZ, PX_TIX, PX_TIY, PX_TIZ };
+#define PXU(k) pxu[(k) * RT_WAVE]
+#define PXF(k) pxf[(k) * RT_WAVE]
     uint32_t rng = 0;
-    int sample = 0;
-    rt_f3 totalIncoming = rt_v3s(0.0f);
 
     bool pathActive = false; /* a ray is waiting to be intersected / is being intersected */
     bool inTrav = false;     /* suspended inside traverse() */
@@ -629,15 +632,17 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
                     /* RC:550-556 */
                     const uint32_t pixelCoordX = (uint32_t)(uvx * (float)a.W);
                     const uint32_t pixelCoordY = (uint32_t)(uvy * (float)a.H);
-                    pixelIndex = pixelCoordY * a.W + pixelCoordX;
+                    const uint32_t pixelIndex = pixelCoordY * a.W + pixelCoordX;
                     const rt_f3 fpl = rt_v3(uvx - 0.5f, uvy - 0.5f, 1.0f) * rt_v3(a.viewParams[0], a.viewParams[1], a.viewParams[2]);
-                    focusPoint = rt_mul_point(a.cam, fpl, 1.0f);
-                    pixLinear = (uint32_t)lrow * a.W + (uint32_t)x;
-                    pixSegStart = segments;
-                    frame = a.frame0;
-                    rng = pixelIndex + (uint32_t)frame * 719393u + (uint32_t)a.seed; /* RC:552 */
-                    sample = 0;
-                    totalIncoming = rt_v3s(0.0f);
+                    const rt_f3 focusPoint = rt_mul_point(a.cam, fpl, 1.0f);
+                    PXU(PX_INDEX) = pixelIndex;
+                    PXU(PX_LINEAR) = (uint32_t)lrow * a.W + (uint32_t)x;
+                    PXU(PX_SEGSTART) = segments;
+                    PXU(PX_FRAME) = (uint32_t)a.frame0;
+                    PXU(PX_SAMPLE) = 0;
+                    PXF(PX_FPX) = focusPoint.x; PXF(PX_FPY) = focusPoint.y; PXF(PX_FPZ) = focusPoint.z;
+                    PXF(PX_TIX) = 0.0f; PXF(PX_TIY) = 0.0f; PXF(PX_TIZ) = 0.0f;
+                    rng = pixelIndex + (uint32_t)a.frame0 * 719393u + (uint32_t)a.seed; /* RC:552 */
                     pathActive = false;
                     inTrav = false;
                     laneDone = false;
@@ -650,12 +655,15 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
         if (idle == ~0ull) break; /* nothing left anywhere */
         if (!laneDone) {
         phase_mark<STATS>(st, PH_LOOP);
-        const size_t pixOff = (size_t)pixLinear * 4;
         if (!inTrav) {
             if (!pathActive) {
+                int sample = (int)PXU(PX_SAMPLE);
                 if (sample == a.spp) {
                     /* RC:581 + RCC:18-23: finish this frame of this pixel */
-                    rt_f3 col = totalIncoming / (float)a.spp;
+                    const uint32_t pixLinear = PXU(PX_LINEAR);
+                    const size_t pixOff = (size_t)pixLinear * 4;
+                    int frame = (int)PXU(PX_FRAME);
+                    rt_f3 col = rt_v3(PXF(PX_TIX), PXF(PX_TIY), PXF(PX_TIZ)) / (float)a.spp;
                     if (frame == frameEnd - 1) {
                         float4 o = make_float4(col.x, col.y, col.z, 1.0f);
                         *reinterpret_cast<float4*>(a.frameRender + pixOff) = o;
@@ -673,12 +681,14 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
                         laneDone = true;
                         if (a.tileCost) { /* longest serial chain of this tile's pixels: next frame's queue order */
                             const uint32_t prow = pixLinear / a.W, pcol = pixLinear - prow * a.W;
-                            atomicMax(a.tileCost + (prow >> 3) * (uint32_t)a.tilesX + (pcol >> 3), (segments - pixSegStart) / (uint32_t)a.nFrames);
+                            atomicMax(a.tileCost + (prow >> 3) * (uint32_t)a.tilesX + (pcol >> 3), (segments - PXU(PX_SEGSTART)) / (uint32_t)a.nFrames);
                         }
                     } else {
-                        rng = pixelIndex + (uint32_t)frame * 719393u + (uint32_t)a.seed;
+                        rng = PXU(PX_INDEX) + (uint32_t)frame * 719393u + (uint32_t)a.seed;
                         sample = 0;
-                        totalIncoming = rt_v3s(0.0f);
+                        PXU(PX_FRAME) = (uint32_t)frame;
+                        PXU(PX_SAMPLE) = 0;
+                        PXF(PX_TIX) = 0.0f; PXF(PX_TIY) = 0.0f; PXF(PX_TIZ) = 0.0f;
                     }
                 }
                 if (!laneDone && sample < a.spp) {
@@ -687,15 +697,16 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
                     rt_f2 dj = rand_circle(&rng);
                     rt_f3 rayOrigin = camOrigin + camRight * (dj.x * a.defocus * invNumPixelsX) + camUp * (dj.y * a.defocus * invNumPixelsX);
                     rt_f2 jj = rand_circle(&rng);
+                    const rt_f3 focusPoint = rt_v3(PXF(PX_FPX), PXF(PX_FPY), PXF(PX_FPZ));
                     rt_f3 jfp = focusPoint + camRight * (jj.x * a.diverge * invNumPixelsX) + camUp * (jj.y * a.diverge * invNumPixelsX);
                     rpos = rayOrigin;
                     rdir = rt_normalize(jfp - rayOrigin);
                     transmittance = rt_v3s(1.0f);
                     pathLight = rt_v3s(0.0f);
                     bounce = 0;
-                    sample++;
+                    PXU(PX_SAMPLE) = (uint32_t)(sample + 1);
                     if (a.maxBounce >= 0) pathActive = true;                /* RC:485: the loop runs for i = 0 */
-                    else totalIncoming = totalIncoming + rt_v3s(0.0f);      /* Trace returned 0 (RC:578) */
+                    else { PXF(PX_TIX) = PXF(PX_TIX) + 0.0f; PXF(PX_TIY) = PXF(PX_TIY) + 0.0f; PXF(PX_TIZ) = PXF(PX_TIZ) + 0.0f; } /* Trace returned 0 (RC:578) */
                 }
             }
             if (pathActive) {
@@ -766,7 +777,9 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
                 }
             }
             if (endPath) {
-                totalIncoming = totalIncoming + pathLight; /* RC:578 */
+                PXF(PX_TIX) = PXF(PX_TIX) + pathLight.x; /* RC:578: totalIncomingLight += Trace(...) */
+                PXF(PX_TIY) = PXF(PX_TIY) + pathLight.y;
+                PXF(PX_TIZ) = PXF(PX_TIZ) + pathLight.z;
                 pathActive = false;
             }
         }
