@@ -248,6 +248,14 @@ int rt_build_bvh(const float* verts, const float* normals, int n_verts,
                  const int32_t* indices, int n_indices, int quality,
                  RtBVHNode* out_nodes, int* out_n_nodes,
                  RtTriangle* out_tris, RtBvhStats* out_stats);
+/* The same builder on n_threads host threads (0 = auto: RT_BVH_THREADS or the core count,
+ * at most 16).  Output is byte-identical to rt_build_bvh for every thread count: big nodes
+ * are swept in ordered chunks reduced in order, subtrees are built privately and numbered
+ * afterwards in the reference's allocation order.  rt_build_bvh itself uses the auto setting. */
+int rt_build_bvh_mt(const float* verts, const float* normals, int n_verts,
+                    const int32_t* indices, int n_indices, int quality, int n_threads,
+                    RtBVHNode* out_nodes, int* out_n_nodes,
+                    RtTriangle* out_tris, RtBvhStats* out_stats);
 /* RCM:183-190 UpdateCameraParams: fills viewParams from (fovDeg, aspect, focusDist). */
 int rt_camera_view_params(float fov_deg, float aspect, float focus_distance, float out_view_params[3]);
 

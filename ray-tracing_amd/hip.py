@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "rt_local_to_global_row", "rt_bind_render_targets", "rt_get_render_targets", "rt_upload_scene", "rt_update_models",
     "rt_update_spheres", "rt_set_params", "rt_reset_accumulation", "rt_render_frame", "rt_render_frames",
     "rt_synchronize", "rt_get_frame", "rt_read_frame", "rt_read_accumulated", "rt_timer_begin", "rt_timer_end",
-    "rt_enable_stats", "rt_reset_counters", "rt_get_counters", "rt_build_bvh", "rt_camera_view_params", "rt_version",
+    "rt_enable_stats", "rt_reset_counters", "rt_get_counters", "rt_build_bvh", "rt_build_bvh_mt", "rt_camera_view_params", "rt_version",
     "rt_debug_intersect", "rt_debug_math_eval", "rt_debug_phase_profile",
 ]
 
@@ -37,6 +37,8 @@ class HipApi(abi.CApi):
         "timer_begin": (C.c_int, [C.c_void_p]),
         "timer_end": (C.c_int, [C.c_void_p]),
         "enable_stats": (C.c_int, [C.c_void_p, C.c_int]),
+        "build_bvh_mt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.POINTER(C.c_int), C.c_void_p, C.POINTER(abi.RtBvhStats)]),
         "debug_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
         "debug_math_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
         "debug_phase_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -50,6 +52,22 @@ class HipApi(abi.CApi):
         super().__init__(path, "rt_")
         for name, (res, args) in self._EXTRA.items():
             self._bind(name, res, args)
+
+    def build_bvh_arrays_mt(self, verts, normals, indices, quality=abi.BVH_QUALITY_HIGH, threads=0):
+        """rt_build_bvh_mt: same output as build_bvh_arrays, on `threads` host threads."""
+        verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+        normals = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+        indices = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1)
+        ntri = len(indices) // 3
+        nodes = np.zeros(2 * max(1, ntri), dtype=abi.node_dtype)
+        tris = np.zeros(ntri, dtype=abi.triangle_dtype)
+        n_nodes = C.c_int(0)
+        stats = abi.RtBvhStats()
+        rc = self.build_bvh_mt(verts.ctypes.data, normals.ctypes.data, len(verts), indices.ctypes.data, len(indices),
+                               int(quality), int(threads), nodes.ctypes.data, C.byref(n_nodes), tris.ctypes.data, C.byref(stats))
+        if rc != abi.RT_OK:
+            raise abi.RtError(rc, "build_bvh_mt failed")
+        return nodes[: n_nodes.value].copy(), tris, stats.as_dict()
 
     def create_tracer(self, device_id=0):
         h = C.c_void_p()

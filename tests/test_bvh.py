@@ -111,3 +111,16 @@ def test_bvh_traversal_equals_bruteforce(pkg, orc, cfg, kw):
             assert a[2] == b[1], (i, a[2], b[1])
     assert hits > n // 4
     tr.close()
+
+
+@pytest.mark.parametrize("threads", [1, 2, 3, 7, 16])
+def test_parallel_builder_is_byte_identical_for_any_thread_count(pkg, api, orc, threads):
+    """rt_build_bvh_mt: chunk-ordered sweeps + privately built subtrees numbered afterwards in the
+    reference's allocation order -> the same bytes as the literal single-thread restatement."""
+    for mesh, q in ((pkg.meshes.icosphere(5, 1.0, 11), 1), (pkg.meshes.icosphere(5, 1.0, 12), 0), (pkg.meshes.rounded_cube(40), 1)):
+        assert mesh.triangle_count > 8192  # above the threshold where threads are used at all
+        n0, t0, s0 = orc.build_bvh_arrays(mesh.vertices, mesh.normals, mesh.triangles, q)
+        n1, t1, s1 = api.build_bvh_arrays_mt(mesh.vertices, mesh.normals, mesh.triangles, q, threads)
+        assert n0.tobytes() == n1.tobytes() and t0.tobytes() == t1.tobytes()
+        s0.pop("timeMs"), s1.pop("timeMs")
+        assert s0 == s1
