@@ -227,6 +227,19 @@ int rt_get_frame(const RtContext* ctx);
 int rt_read_frame(RtContext* ctx, float* rgba, size_t bytes);
 int rt_read_accumulated(RtContext* ctx, float* rgba, size_t bytes);
 
+/* ---- display pass (RayTraceDisplay.cs:9-23 + Display.shader:42-47) ---------------- */
+/* What the reference puts on screen: tex / Frame, where the caller passes
+ * tex = accumulated (use_accumulated != 0, Frame = numAccumulatedFrames — the POST-increment
+ * counter, so N accumulated frames are divided by N+1, the reference's off-by-one) or the last
+ * frame (Frame = 1).  Host output, local rows, row 0 = bottom; synchronises. */
+int rt_display(RtContext* ctx, int frame, int use_accumulated, float* rgba, size_t bytes);
+/* The same followed by the linear->sRGB conversion and 8-bit quantisation of the back buffer
+ * (Unity linear colour space); RGBA8, alpha 255; flip_y != 0 writes the top row first (PNG order). */
+int rt_display_srgb8(RtContext* ctx, int frame, int use_accumulated, int flip_y, uint8_t* rgba8, size_t bytes);
+/* Checkpoint/resume: restore the accumulation sum saved with rt_read_accumulated (the frame
+ * counter and seed travel in RtParams).  local_rows*W*16 bytes. */
+int rt_write_accumulated(RtContext* ctx, const float* rgba, size_t bytes);
+
 /* ---- device timing ---------------------------------------------------------- */
 /* HIP events recorded on the stream the kernels are launched on: the device
  * time between rt_timer_begin and rt_timer_end is added to RtCounters.gpuMs

@@ -278,6 +278,15 @@ RT_HD rt_f3 rt_mul_point(const float* m, rt_f3 v, float w)
                  m[2] * v.x + m[6] * v.y + m[10] * v.z + m[14] * w);
 }
 
+/* linear -> sRGB transfer (what Unity's linear colour space applies when the Display pass
+ * writes to the sRGB back buffer), then 8-bit quantisation with round-half-up */
+RT_HD float rt_linear_to_srgb(float c)
+{
+    c = rt_saturate(c);
+    return c <= 0.0031308f ? 12.92f * c : 1.055f * rt_pow(c, 1.0f / 2.4f) - 0.055f;
+}
+RT_HD uint32_t rt_srgb8(float c) { return (uint32_t)(rt_linear_to_srgb(c) * 255.0f + 0.5f); }
+
 /* ------------------------------------------------------------------- RNG */
 /* PCG hash step — RC:127-133 */
 RT_HD uint32_t rt_next_random(uint32_t* state)

@@ -817,6 +817,38 @@ int oracle_read_accumulated(OracleContext* ctx, float* rgba, size_t bytes)
     memcpy(rgba, ctx->accumulated.data(), bytes);
     return RT_OK;
 }
+/* Display.shader:42-47 with RayTraceDisplay.cs:14-16 choosing texture and Frame */
+int oracle_display(OracleContext* ctx, int frame, int use_accumulated, float* rgba, size_t bytes)
+{
+    if (!ctx || !rgba || frame == 0) return RT_ERR_INVALID_ARG;
+    const std::vector<float>& src = use_accumulated ? ctx->accumulated : ctx->frameRender;
+    if (bytes != src.size() * 4) return RT_ERR_INVALID_ARG;
+    for (size_t i = 0; i < src.size(); i++) rgba[i] = rt_div(src[i], (float)frame); /* float4 / int */
+    return RT_OK;
+}
+int oracle_display_srgb8(OracleContext* ctx, int frame, int use_accumulated, int flip_y, uint8_t* rgba8, size_t bytes)
+{
+    if (!ctx || !rgba8 || frame == 0) return RT_ERR_INVALID_ARG;
+    const std::vector<float>& src = use_accumulated ? ctx->accumulated : ctx->frameRender;
+    if (bytes != src.size()) return RT_ERR_INVALID_ARG;
+    const float inv = rt_rcp((float)frame);
+    for (int y = 0; y < ctx->H; y++)
+        for (int x = 0; x < ctx->W; x++) {
+            size_t i = ((size_t)y * ctx->W + x) * 4;
+            size_t o = ((size_t)(flip_y ? ctx->H - 1 - y : y) * ctx->W + x) * 4;
+            rgba8[o + 0] = (uint8_t)rt_srgb8(src[i + 0] * inv);
+            rgba8[o + 1] = (uint8_t)rt_srgb8(src[i + 1] * inv);
+            rgba8[o + 2] = (uint8_t)rt_srgb8(src[i + 2] * inv);
+            rgba8[o + 3] = 255;
+        }
+    return RT_OK;
+}
+int oracle_write_accumulated(OracleContext* ctx, const float* rgba, size_t bytes)
+{
+    if (!ctx || !rgba || bytes != ctx->accumulated.size() * 4) return RT_ERR_INVALID_ARG;
+    memcpy(ctx->accumulated.data(), rgba, bytes);
+    return RT_OK;
+}
 int oracle_reset_counters(OracleContext* ctx)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;

@@ -127,6 +127,9 @@ class CApi:
         "get_frame": (C.c_int, [C.c_void_p]),
         "read_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
         "read_accumulated": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+        "display": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+        "display_srgb8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+        "write_accumulated": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
         "reset_counters": (C.c_int, [C.c_void_p]),
         "get_counters": (C.c_int, [C.c_void_p, C.POINTER(RtCounters)]),
         "build_bvh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
@@ -259,6 +262,21 @@ class Tracer:
 
     def read_accumulated(self):
         return self._read(self.api.read_accumulated)
+
+    def display(self, frame, use_accumulated=True):
+        """Display.shader: tex / Frame (HDR float image, local rows, row 0 = bottom)."""
+        out = np.empty((self.local_rows(), self.width, 4), dtype=np.float32)
+        self._check(self.api.display(self.h, int(frame), 1 if use_accumulated else 0, out.ctypes.data, out.nbytes))
+        return out
+
+    def display_srgb8(self, frame, use_accumulated=True, flip_y=True):
+        out = np.empty((self.local_rows(), self.width, 4), dtype=np.uint8)
+        self._check(self.api.display_srgb8(self.h, int(frame), 1 if use_accumulated else 0, 1 if flip_y else 0, out.ctypes.data, out.nbytes))
+        return out
+
+    def write_accumulated(self, image):
+        image = np.ascontiguousarray(image, dtype=np.float32)
+        self._check(self.api.write_accumulated(self.h, image.ctypes.data, image.nbytes))
 
     def reset_counters(self):
         self._check(self.api.reset_counters(self.h))

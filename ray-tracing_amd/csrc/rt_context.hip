@@ -893,6 +893,71 @@ int rt_read_accumulated(RtContext* ctx, float* rgba, size_t bytes)
     return read_target(ctx, ctx ? (ctx->boundAccum ? ctx->boundAccum : ctx->ownAccum) : nullptr, rgba, bytes);
 }
 
+/* ---- display pass + checkpoint ------------------------------------------------ */
+static int display_common(RtContext* ctx, int frame, int use_accumulated, const float** src)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (ctx->W == 0) return fail(ctx, RT_ERR_STATE, "display before rt_resize");
+    if (frame == 0) return fail(ctx, RT_ERR_INVALID_ARG, "display: Frame must not be 0");
+    *src = use_accumulated ? (ctx->boundAccum ? ctx->boundAccum : ctx->ownAccum) : (ctx->boundFrame ? ctx->boundFrame : ctx->ownFrame);
+    return RT_OK;
+}
+
+int rt_display(RtContext* ctx, int frame, int use_accumulated, float* rgba, size_t bytes)
+{
+    const float* src = nullptr;
+    int rc = display_common(ctx, frame, use_accumulated, &src);
+    if (rc) return rc;
+    const size_t n = (size_t)ctx->localRows * ctx->W;
+    if (!rgba || bytes != n * 16) return fail(ctx, RT_ERR_INVALID_ARG, "rt_display: need exactly %zu bytes", n * 16);
+    if (n == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float4* tmp = nullptr;
+    HIP_TRY(ctx, hipMalloc(&tmp, bytes));
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rtk::rt_display_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const float4*)src, tmp, n, frame);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(rgba, tmp, bytes, hipMemcpyDeviceToHost);
+    hipFree(tmp);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_display: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_display_srgb8(RtContext* ctx, int frame, int use_accumulated, int flip_y, uint8_t* rgba8, size_t bytes)
+{
+    const float* src = nullptr;
+    int rc = display_common(ctx, frame, use_accumulated, &src);
+    if (rc) return rc;
+    const size_t n = (size_t)ctx->localRows * ctx->W;
+    if (!rgba8 || bytes != n * 4) return fail(ctx, RT_ERR_INVALID_ARG, "rt_display_srgb8: need exactly %zu bytes", n * 4);
+    if (n == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t* tmp = nullptr;
+    HIP_TRY(ctx, hipMalloc(&tmp, bytes));
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rtk::rt_display_srgb8_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const float4*)src, tmp, ctx->W, ctx->localRows, frame, flip_y);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(rgba8, tmp, bytes, hipMemcpyDeviceToHost);
+    hipFree(tmp);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_display_srgb8: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_write_accumulated(RtContext* ctx, const float* rgba, size_t bytes)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    const size_t want = (size_t)ctx->localRows * ctx->W * 16;
+    if (!rgba || bytes != want) return fail(ctx, RT_ERR_INVALID_ARG, "rt_write_accumulated: need exactly %zu bytes, got %zu", want, bytes);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (bytes) HIP_TRY(ctx, hipMemcpy(ctx->boundAccum ? ctx->boundAccum : ctx->ownAccum, rgba, bytes, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
 int rt_enable_stats(RtContext* ctx, int enabled)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");

@@ -886,6 +886,33 @@ __global__ void __launch_bounds__(1024) rt_order_kernel(const uint32_t* cost, ui
     }
 }
 
+/* Display pass — Display.shader:42-47: col = tex / Frame (the blit of RayTraceDisplay.cs:9-23).
+ * SRGB8: additionally the linear->sRGB conversion + 8-bit quantisation the back buffer applies. */
+__global__ void rt_display_kernel(const float4* src, float4* dst, size_t n, int frame)
+{
+    const float inv = rt_rcp((float)frame);
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float4 v = src[i];
+        dst[i] = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+    }
+}
+__global__ void rt_display_srgb8_kernel(const float4* src, uint32_t* dst, int width, int rows, int frame, int flipY)
+{
+    const float inv = rt_rcp((float)frame);
+    const size_t n = (size_t)width * rows;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float4 v = src[i];
+        uint32_t r = rt_srgb8(v.x * inv), g = rt_srgb8(v.y * inv), b = rt_srgb8(v.z * inv);
+        size_t row = i / width, col = i - row * width;
+        size_t o = flipY ? ((size_t)(rows - 1) - row) * width + col : i;
+        dst[o] = r | (g << 8) | (b << 16) | 0xff000000u;
+    }
+}
+
 /* ResetAccumulated — RCC:26-32 */
 __global__ void rt_reset_kernel(float4* accum, size_t n)
 {

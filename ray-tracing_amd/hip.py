@@ -18,7 +18,8 @@ ABI_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_resize", "rt_set_partition", "rt_local_rows",
     "rt_local_to_global_row", "rt_bind_render_targets", "rt_get_render_targets", "rt_upload_scene", "rt_update_models",
     "rt_update_spheres", "rt_set_params", "rt_reset_accumulation", "rt_render_frame", "rt_render_frames",
-    "rt_synchronize", "rt_get_frame", "rt_read_frame", "rt_read_accumulated", "rt_timer_begin", "rt_timer_end",
+    "rt_synchronize", "rt_get_frame", "rt_read_frame", "rt_read_accumulated", "rt_display", "rt_display_srgb8",
+    "rt_write_accumulated", "rt_timer_begin", "rt_timer_end",
     "rt_enable_stats", "rt_reset_counters", "rt_get_counters", "rt_build_bvh", "rt_build_bvh_mt", "rt_camera_view_params", "rt_version",
     "rt_debug_intersect", "rt_debug_math_eval", "rt_debug_phase_profile",
 ]
