@@ -758,7 +758,7 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
     fill_args(ctx, frame0, nFrames, a);
     int tiles = a.tilesX * a.tilesY;
     if (tiles == 0) return RT_OK;
-    const size_t stackBytes = (size_t)(ctx->stackEntries + RT_PIXEL_FIELDS) * RT_WAVE * sizeof(uint32_t);
+    const size_t stackBytes = (size_t)(ctx->stackEntries + RT_PIXEL_FIELDS) * RT_WAVE * sizeof(uint32_t) + (RT_COOP_FETCH ? 4 * 1040 : 0);
     a.stackEntries = ctx->stackEntries;
     /* Persistent launch: as many single-wave workgroups as the chip keeps resident
      * (occupancy query x CUs), never more than there are tiles.  The first `grid` tiles are

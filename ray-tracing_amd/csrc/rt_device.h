@@ -30,6 +30,9 @@
 #define RT_STACK_DEPTH 34            /* >= RT_MAX_BVH_DEPTH + 2 */
 #define RT_COUNTER_SLOTS 1024        /* counters are spread over slots to avoid same-address atomics */
 #define RT_PIXEL_FIELDS 11
+#ifndef RT_COOP_FETCH
+#define RT_COOP_FETCH 0
+#endif
 #define RT_N_PHASES 12
 #define RT_COUNTER_FIELDS (8 + 2 * RT_N_PHASES)
 
