@@ -108,7 +108,7 @@ class Transform:
 
 def matrix_to_abi(m):
     """4x4 (row, col) -> Unity Matrix4x4 memory order (column-major 16 floats)."""
-    return np.asarray(m, dtype=np.float64).T.reshape(16).astype(np.float32)
+    return (np.asarray(m, dtype=np.float64).T.reshape(16) + 0.0).astype(np.float32)  # + 0.0: no negative zeros
 
 
 class Camera:
