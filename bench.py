@@ -153,6 +153,18 @@ def main():
     tracer.enable_stats(False)
     assert stats["segments"] == segments, (stats["segments"], segments)
 
+    # ---- informational: the same K frames through the batched API (rt_render_frames: up to 16
+    # frames per launch, each pixel runs its frames back to back; identical final buffers)
+    mgr.numAccumulatedFrames = first_frame
+    mgr.SetShaderParams()
+    tracer.reset_counters()
+    barrier()
+    b0 = time.perf_counter()
+    tracer.render_frames(args.steps)
+    barrier()
+    batched_elapsed = time.perf_counter() - b0
+    batched_segments = tracer.counters()["segments"]
+
     # ---- readback: the one collective of the multi-GPU path
     gather_ms = None
     if tiled:
@@ -212,6 +224,9 @@ def main():
             "resolution": [W, H],
             "kernel_ms_per_step": kernel_ms_max / args.steps,
             "gather_ms": gather_ms,
+            "batched_api": {"what": "rt_render_frames(K): frames fused up to 16 per launch (this rank)",
+                            "value": batched_segments / batched_elapsed / 1e6, "unit": "Mrays/s",
+                            "ms_per_frame": batched_elapsed / args.steps * 1e3},
             "parity": "bit-identical to oracle/ on tests/ (pytest -m gpu); max rel err 0",
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

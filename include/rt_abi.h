@@ -213,8 +213,10 @@ int rt_reset_accumulation(RtContext* ctx);
  * by rt_set_params), then increments the counter if accumulate (RCM:94).
  * Asynchronous: returns after enqueueing. */
 int rt_render_frame(RtContext* ctx);
-/* n consecutive frames Frame, Frame+1, ... (benchmark/batch helper; identical
- * to n calls of rt_render_frame, accumulation order preserved). */
+/* n consecutive frames Frame, Frame+1, ... : the same final FrameRender / AccumulatedRender
+ * as n calls of rt_render_frame (same seeds, same per-pixel order of additions), but when
+ * accumulating the frames are batched, up to 16 per launch, each pixel running its frames
+ * back to back (RT_FUSE_FRAMES=0 in the environment restores one launch per frame). */
 int rt_render_frames(RtContext* ctx, int n);
 /* Wait for all enqueued work of this context. */
 int rt_synchronize(RtContext* ctx);

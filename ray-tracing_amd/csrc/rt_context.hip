@@ -20,6 +20,7 @@
 
 #include "rt_kernels.h"
 
+#define RT_MAX_FUSED_FRAMES 16
 #define RT_VERSION_STRING "raytrace_hip gfx950 abi=1"
 
 static thread_local char g_err[512] = "";
@@ -74,11 +75,13 @@ struct RtContext {
     int orderTiles = 0;             /* tiles the two arrays are sized for; 0 = none */
     bool orderValid = false;
     long long framesSinceResize = 0;
+    long long nextSortAt = 1;
     bool lptEnabled = true;
     int numCUs = 256;
     int occPerCU[4] = {0, 0, 0, 0};
     size_t occBytes[4] = {0, 0, 0, 0};
     bool verbose = false;
+    bool fuseFrames = true; /* rt_render_frames(n): up to RT_MAX_FUSED_FRAMES frames per launch (RT_FUSE_FRAMES=0: one launch per frame) */
     int gridOverride = 0; /* test hook: force the persistent grid size */
     bool stats = false;
     uint64_t pixelFrames = 0;
@@ -163,6 +166,7 @@ int rt_create(int device_id, RtContext** out)
     memset(&ctx->params, 0, sizeof(ctx->params));
     if (const char* g = getenv("RT_GRID")) ctx->gridOverride = atoi(g); /* tuning hook */
     if (getenv("RT_VERBOSE")) ctx->verbose = true;
+    if (const char* f = getenv("RT_FUSE_FRAMES")) ctx->fuseFrames = atoi(f) != 0;
     if (const char* l = getenv("RT_LPT")) ctx->lptEnabled = atoi(l) != 0;
     *out = ctx;
     return RT_OK;
@@ -786,10 +790,12 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         ctx->orderTiles = tiles;
         ctx->orderValid = false;
         ctx->framesSinceResize = 0;
+        ctx->nextSortAt = 1;
     }
     if (ctx->lptEnabled) {
         const long long f = ctx->framesSinceResize;
-        if (f > 0 && (f & (f - 1)) == 0) { /* re-sort after frames 1, 2, 4, 8, ... */
+        if (f >= ctx->nextSortAt) { /* re-sort once 1, 2, 4, 8, ... frames have been recorded */
+            while (ctx->nextSortAt <= f) ctx->nextSortAt *= 2;
             hipLaunchKernelGGL(rtk::rt_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->dTileCost, ctx->dTileOrder, tiles);
             HIP_TRY(ctx, hipGetLastError());
             ctx->orderValid = true;
@@ -835,6 +841,20 @@ int rt_render_frames(RtContext* ctx, int n)
     if (rc) return rc;
     if (n < 0) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render_frames: n < 0");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->fuseFrames && ctx->params.accumulate) {
+        /* Batched form: each pixel runs its frames back to back inside one launch — same Frame
+         * seeds, same order of additions into the sum, FrameRender = the last frame — so the
+         * chip-wide drain at the end of a launch is paid once per batch instead of once per
+         * frame.  Batches are capped to keep launches short. */
+        while (n > 0) {
+            const int k = n < RT_MAX_FUSED_FRAMES ? n : RT_MAX_FUSED_FRAMES;
+            rc = launch_frames(ctx, ctx->frame, k);
+            if (rc) return rc;
+            ctx->frame += k;
+            n -= k;
+        }
+        return RT_OK;
+    }
     for (int i = 0; i < n; i++) {
         rc = launch_frames(ctx, ctx->frame, 1);
         if (rc) return rc;

@@ -3,20 +3,23 @@
  *
  * Replaces the reference's HLSL kernels RayTrace / ResetAccumulated
  * (Assets/Scripts/Tracer/RayCompute.compute:10-32) and everything they call in
- * RayCommon.hlsl ("RC"), with the same per-pixel results:
- *   - one wave64 = one 8x8 pixel tile (the reference's [numthreads(8,8,1)] group
- *     happens to be exactly one CDNA wavefront);
- *   - each lane owns one pixel and runs that pixel's serial RNG chain (quirk Q13);
- *     instead of the reference's nested sample/bounce loops, a lane whose path
- *     ends immediately starts its pixel's next sample (and next frame), so the
- *     wave stays converged on the expensive part — the scene intersection —
- *     while lanes sit at different samples/bounces;
+ * RayCommon.hlsl ("RC"), with the same per-pixel results (DESIGN.md §4):
+ *   - persistent single-wave workgroups; a lane owns one pixel at a time and runs
+ *     that pixel's serial RNG chain (quirk Q13), taking the next unassigned pixel of
+ *     the wave's current 8x8 tile (tiles come from a global atomic queue, longest
+ *     pixel chains first) as soon as its pixel is finished;
+ *   - instead of the reference's nested sample / bounce / model / node loops a lane
+ *     is a state machine and the wave executes one kind of work at a time for the
+ *     lanes that need it: camera ray -> spheres (two-phase) + conservative
+ *     world-space root filter over the models -> resumable traversal with
+ *     majority-phase scheduling and suspension -> shading;
  *   - the per-ray BVH order (near child first, strict '<', RC:256,274-281) is
  *     the reference's, so closest-hit ties resolve identically; the near child
  *     stays in a register instead of being pushed and popped, the far child goes
  *     to a per-lane stack in LDS laid out [level][lane] (bank = lane, conflict
- *     free for ds_read/write_b32);
- *   - spheres / models / uniforms are wave-uniform and come through scalar loads;
+ *     free for ds_read/write_b32); pixel bookkeeping is parked in LDS next to it;
+ *   - spheres / model matrices / filter boxes / uniforms are wave-uniform and come
+ *     through scalar loads (constant address space);
  *   - no MFMA: branchy scalar fp32, there is no contraction to map.
  *
  * Arithmetic follows include/rt_math.h (strict fp32, no contraction) so the
@@ -31,7 +34,7 @@
 #include "../../include/rt_math.h"
 #include "rt_device.h"
 
-/* waves per SIMD the register allocator must leave room for (launch_bounds 2nd argument) */
+/* Tuning knobs (values measured on MI355X). */
 /* traverse() is left once active <= entered * NUM/DEN lanes are still traversing */
 #ifndef RT_SUSPEND_NUM
 #define RT_SUSPEND_NUM 3
@@ -41,6 +44,7 @@
 #ifndef RT_COOP_FETCH
 #define RT_COOP_FETCH 0
 #endif
+/* waves per SIMD the register allocator must leave room for (launch_bounds 2nd argument) */
 #ifndef RT_MIN_WAVES_PER_SIMD
 #define RT_MIN_WAVES_PER_SIMD 5
 #endif
