@@ -149,20 +149,25 @@ int rt_create(int device_id, RtContext** out)
     if (device_id < 0 || device_id >= n) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: device %d out of range [0,%d)", device_id, n);
     RtContext* ctx = new RtContext();
     ctx->device = device_id;
-    HIP_TRY(ctx, hipSetDevice(device_id));
-    {
+    auto init = [&]() -> int {
+        HIP_TRY(ctx, hipSetDevice(device_id));
         hipDeviceProp_t prop;
         HIP_TRY(ctx, hipGetDeviceProperties(&prop, device_id));
         ctx->numCUs = prop.multiProcessorCount;
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking));
+        ctx->stream = ctx->ownStream;
+        HIP_TRY(ctx, hipMalloc(&ctx->dCounters, sizeof(unsigned long long) * RT_COUNTER_SLOTS * RT_COUNTER_FIELDS));
+        HIP_TRY(ctx, hipMemset(ctx->dCounters, 0, sizeof(unsigned long long) * RT_COUNTER_SLOTS * RT_COUNTER_FIELDS));
+        HIP_TRY(ctx, hipMalloc(&ctx->dTileQueue, sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMemset(ctx->dTileQueue, 0, sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipEventCreate(&ctx->evStart));
+        HIP_TRY(ctx, hipEventCreate(&ctx->evStop));
+        return RT_OK;
+    };
+    if (int rc = init()) { /* the message stays readable through rt_last_error(NULL) */
+        rt_destroy(ctx);
+        return rc;
     }
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking));
-    ctx->stream = ctx->ownStream;
-    HIP_TRY(ctx, hipMalloc(&ctx->dCounters, sizeof(unsigned long long) * RT_COUNTER_SLOTS * RT_COUNTER_FIELDS));
-    HIP_TRY(ctx, hipMemset(ctx->dCounters, 0, sizeof(unsigned long long) * RT_COUNTER_SLOTS * RT_COUNTER_FIELDS));
-    HIP_TRY(ctx, hipMalloc(&ctx->dTileQueue, sizeof(unsigned long long)));
-    HIP_TRY(ctx, hipMemset(ctx->dTileQueue, 0, sizeof(unsigned long long)));
-    HIP_TRY(ctx, hipEventCreate(&ctx->evStart));
-    HIP_TRY(ctx, hipEventCreate(&ctx->evStop));
     memset(&ctx->params, 0, sizeof(ctx->params));
     if (const char* g = getenv("RT_GRID")) ctx->gridOverride = atoi(g); /* tuning hook */
     if (getenv("RT_VERBOSE")) ctx->verbose = true;
@@ -762,7 +767,7 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
     fill_args(ctx, frame0, nFrames, a);
     int tiles = a.tilesX * a.tilesY;
     if (tiles == 0) return RT_OK;
-    const size_t stackBytes = (size_t)(ctx->stackEntries + RT_PIXEL_FIELDS) * RT_WAVE * sizeof(uint32_t) + (RT_COOP_FETCH ? 4 * 1040 : 0);
+    const size_t stackBytes = (size_t)(ctx->stackEntries + RT_PIXEL_FIELDS) * RT_WAVE * sizeof(uint32_t);
     a.stackEntries = ctx->stackEntries;
     /* Persistent launch: as many single-wave workgroups as the chip keeps resident
      * (occupancy query x CUs), never more than there are tiles.  The first `grid` tiles are
@@ -807,9 +812,9 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
     if (ctx->verbose) fprintf(stderr, "[raytrace_hip] launch variant=%d tiles=%d grid=%d perCU=%d lds=%zu\n", variant, tiles, grid, ctx->occPerCU[variant], stackBytes);
     a.tileQueue = ctx->dTileQueue;
     a.tileQueueBase = ctx->tileQueueNext - (unsigned long long)grid;
-    ctx->tileQueueNext += (unsigned long long)(tiles - grid) + (unsigned long long)grid; /* each wave overshoots once */
     hipLaunchKernelGGL(kern, dim3(grid), dim3(RT_WAVE), stackBytes, ctx->stream, a);
-    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipGetLastError()); /* a refused launch ran no wave: the device counter did not move */
+    ctx->tileQueueNext += (unsigned long long)(tiles - grid) + (unsigned long long)grid; /* each wave overshoots once */
     ctx->pixelFrames += (uint64_t)ctx->localRows * ctx->W * nFrames;
     return RT_OK;
 }
@@ -1043,6 +1048,14 @@ int rt_debug_phase_profile(RtContext* ctx, uint64_t* out, int n)
     return RT_OK;
 }
 
+/* device scratch that is released on every exit path of the two hooks below */
+struct DevScratch {
+    void* p = nullptr;
+    ~DevScratch() { if (p) hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+    float* f() const { return (float*)p; }
+};
+
 int rt_debug_intersect(RtContext* ctx, const float* origins, const float* dirs, int n, float* out10)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
@@ -1050,19 +1063,18 @@ int rt_debug_intersect(RtContext* ctx, const float* origins, const float* dirs, 
     if (n < 0 || (n && (!origins || !dirs || !out10))) return fail(ctx, RT_ERR_INVALID_ARG, "rt_debug_intersect: bad arguments");
     if (n == 0) return RT_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    float *dO = nullptr, *dD = nullptr, *dR = nullptr;
-    HIP_TRY(ctx, hipMalloc(&dO, (size_t)n * 12));
-    HIP_TRY(ctx, hipMalloc(&dD, (size_t)n * 12));
-    HIP_TRY(ctx, hipMalloc(&dR, (size_t)n * 40));
-    HIP_TRY(ctx, hipMemcpy(dO, origins, (size_t)n * 12, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(dD, dirs, (size_t)n * 12, hipMemcpyHostToDevice));
+    DevScratch dO, dD, dR;
+    HIP_TRY(ctx, dO.alloc((size_t)n * 12));
+    HIP_TRY(ctx, dD.alloc((size_t)n * 12));
+    HIP_TRY(ctx, dR.alloc((size_t)n * 40));
+    HIP_TRY(ctx, hipMemcpy(dO.p, origins, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dD.p, dirs, (size_t)n * 12, hipMemcpyHostToDevice));
     KArgs a;
     fill_args(ctx, 1, 1, a);
-    hipLaunchKernelGGL(rtk::rt_debug_intersect_kernel, dim3((n + RT_WAVE - 1) / RT_WAVE), dim3(RT_WAVE), 0, ctx->stream, a, dO, dD, n, dR);
+    hipLaunchKernelGGL(rtk::rt_debug_intersect_kernel, dim3((n + RT_WAVE - 1) / RT_WAVE), dim3(RT_WAVE), 0, ctx->stream, a, dO.f(), dD.f(), n, dR.f());
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(out10, dR, (size_t)n * 40, hipMemcpyDeviceToHost));
-    hipFree(dO); hipFree(dD); hipFree(dR);
+    HIP_TRY(ctx, hipMemcpy(out10, dR.p, (size_t)n * 40, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
@@ -1072,17 +1084,16 @@ int rt_debug_math_eval(RtContext* ctx, int op, const float* x, const float* y, f
     if (n < 0 || (n && (!x || !y || !out))) return fail(ctx, RT_ERR_INVALID_ARG, "rt_debug_math_eval: bad arguments");
     if (n == 0) return RT_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    float *dX = nullptr, *dY = nullptr, *dR = nullptr;
-    HIP_TRY(ctx, hipMalloc(&dX, (size_t)n * 4));
-    HIP_TRY(ctx, hipMalloc(&dY, (size_t)n * 4));
-    HIP_TRY(ctx, hipMalloc(&dR, (size_t)n * 4));
-    HIP_TRY(ctx, hipMemcpy(dX, x, (size_t)n * 4, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(dY, y, (size_t)n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(rtk::rt_debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, op, dX, dY, dR, n);
+    DevScratch dX, dY, dR;
+    HIP_TRY(ctx, dX.alloc((size_t)n * 4));
+    HIP_TRY(ctx, dY.alloc((size_t)n * 4));
+    HIP_TRY(ctx, dR.alloc((size_t)n * 4));
+    HIP_TRY(ctx, hipMemcpy(dX.p, x, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dY.p, y, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rtk::rt_debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, op, dX.f(), dY.f(), dR.f(), n);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(out, dR, (size_t)n * 4, hipMemcpyDeviceToHost));
-    hipFree(dX); hipFree(dY); hipFree(dR);
+    HIP_TRY(ctx, hipMemcpy(out, dR.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -30,9 +30,6 @@
 #define RT_STACK_DEPTH 34            /* >= RT_MAX_BVH_DEPTH + 2 */
 #define RT_COUNTER_SLOTS 1024        /* counters are spread over slots to avoid same-address atomics */
 #define RT_PIXEL_FIELDS 11
-#ifndef RT_COOP_FETCH
-#define RT_COOP_FETCH 0
-#endif
 #define RT_N_PHASES 12
 #define RT_COUNTER_FIELDS (8 + 2 * RT_N_PHASES)
 
@@ -41,6 +38,7 @@
  * indexes bigLeaves {start,count}.  inner: [30:0] = absolute DPair index. */
 #define RT_CODE_LEAF 0x80000000u
 #define RT_CODE_NEXT_MODEL 0x7fffffffu /* traversal state: this model is finished */
+#define RT_CODE_DONE 0x7ffffffeu       /* traversal state: every model visited (inner codes are below this) */
 #define RT_CODE_MAX_INLINE_COUNT 127
 #define RT_CODE_MAX_INLINE_START 0x00ffffffu
 

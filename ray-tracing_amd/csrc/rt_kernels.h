@@ -40,10 +40,6 @@
 #define RT_SUSPEND_NUM 3
 #define RT_SUSPEND_DEN 8
 #endif
-/* quad-cooperative DPair fetch through LDS (global_load_lds) in the traversal's inner step */
-#ifndef RT_COOP_FETCH
-#define RT_COOP_FETCH 0
-#endif
 /* waves per SIMD the register allocator must leave room for (launch_bounds 2nd argument) */
 #ifndef RT_MIN_WAVES_PER_SIMD
 #define RT_MIN_WAVES_PER_SIMD 5
@@ -361,38 +357,46 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
  *
  * Returns true when this lane has visited every model.  With SUSPEND the wave leaves
  * the loop as soon as at most RT_SUSPEND_NUM/RT_SUSPEND_DEN of the lanes that entered are still traversing;
- * the stragglers keep their state in `t`/`h`/LDS and resume at the next call. */
+ * the stragglers keep their state in `t`/`h`/LDS and resume at the next call.  The loop has a
+ * single, wave-uniform exit (finished lanes park in RT_CODE_DONE instead of leaving one by
+ * one), which keeps the loop-carried state in one set of registers. */
 template <bool STATS, bool SUSPEND>
-__device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, SceneHit& h, Trav& t, Stats& st,
-                                         uint32_t* coopSlab = nullptr)
+__device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, SceneHit& h, Trav& t, Stats& st)
 {
-    const int lane = threadIdx.x & 63;
-    (void)lane;
     const DModel* __restrict__ models = a.models;
     const DPair* __restrict__ pairs = a.pairs;
     const DTri* __restrict__ tris = a.tris;
-    const int entered = SUSPEND ? __popcll(__ballot(1)) : 0;
+    const int enteredNum = SUSPEND ? __popcll(__ballot(1)) * RT_SUSPEND_NUM : 0;
     phase_mark<STATS>(st, PH_TRAVERSE_CALL);
-    bool finished = false;
-    for (;;) {
-        /* One kind of work per iteration, chosen for the whole wave: the kind most lanes are
-         * waiting for (wave-uniform branch, so only that code is issued).  A lane deep inside
-         * a big mesh no longer drags 60 idle lanes through its private box tests: it advances
-         * whenever "inner step" is the majority need (every model's root step is one), and
-         * otherwise waits, keeping its state. */
-        const bool atNext = t.cur == RT_CODE_NEXT_MODEL;
-        const bool atLeaf = (t.cur & RT_CODE_LEAF) != 0;
-        const bool atInner = !atNext && !atLeaf;
-        const int nA = __popcll(__ballot(atNext)), nB = __popcll(__ballot(atInner)), nC = __popcll(__ballot(atLeaf));
+    /* One kind of work per iteration, chosen for the whole wave: the kind most lanes are
+     * waiting for (wave-uniform branch, so only that code is issued).  A lane deep inside
+     * a big mesh no longer drags 60 idle lanes through its private box tests: it advances
+     * whenever "inner step" is the majority need (every model's root step is one), and
+     * otherwise waits, keeping its state.
+     * The vote for the next iteration is taken at the bottom of the loop (do-while form, the
+     * only exit is wave-uniform): nobody left, or — SUSPEND — at most RT_SUSPEND_NUM/RT_SUSPEND_DEN
+     * of the lanes that entered are still traversing. */
+    bool atNext, atLeaf, atInner;
+    int nA, nB, nC;
+#define RT_TRAV_VOTE()                                                                                         \
+    do {                                                                                                       \
+        /* a lane between models that has no model left is done: no more demand for phase A */              \
+        if (t.cur == RT_CODE_NEXT_MODEL && !t.cand && (t.m < 63 ? 64 : t.m + 1) >= a.nModels) t.cur = RT_CODE_DONE; \
+        atNext = t.cur == RT_CODE_NEXT_MODEL;                                                                  \
+        atLeaf = (t.cur & RT_CODE_LEAF) != 0;                                                                  \
+        atInner = t.cur < RT_CODE_DONE; /* leaf codes have bit 31 set */                                       \
+        nA = __popcll(__ballot(atNext)), nB = __popcll(__ballot(atInner)), nC = __popcll(__ballot(atLeaf));    \
+    } while (0)
+    RT_TRAV_VOTE();
+    if ((nA + nB + nC) * RT_SUSPEND_DEN > enteredNum) do {
         if (nA >= nB && nA >= nC) {
             if (atNext) { /* ---- A: next model, RC:349-355 */
-                /* next model: the filtered candidates among [0,64), then any model >= 64 in order */
+                /* the filtered candidates among [0,64), then any model >= 64 in order */
                 if (t.cand) {
                     t.m = __ffsll((long long)t.cand) - 1;
                     t.cand &= t.cand - 1;
                 } else {
                     t.m = t.m < 63 ? 64 : t.m + 1;
-                    if (t.m >= a.nModels) { finished = true; break; }
                     if (STATS && !(models[t.m].rootCode & RT_CODE_LEAF)) st.inner++;
                 }
                 t.rootStep = true;
@@ -414,50 +418,12 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
                 if (!(t.cur & RT_CODE_LEAF)) t.linv = rt_v3(rt_rcp(t.ldir.x), rt_rcp(t.ldir.y), rt_rcp(t.ldir.z));
             }
         } else if (nB >= nC) {
-#if RT_COOP_FETCH
-            /* Cooperative node fetch through LDS: every lane in the loop takes part, also those not
-             * at an inner node.  In round r the four lanes of a quad fetch the four 16-byte quarters
-             * of the 64-byte DPair wanted by the quad's lane r with global_load_lds_dwordx4 (LDS
-             * destination = wave-uniform base + lane*16), so one instruction touches 16 cache lines
-             * instead of 64; the owner then reads its record back with four ds_read_b128.  Round
-             * slabs are 1040 B apart, which makes those reads bank-conflict free.  Quads with a lane
-             * outside the loop fall back to the direct loads. */
-            bool fullQuad = false;
-            if constexpr (SUSPEND) { /* the run-to-completion debug form has no slab */
-            const unsigned long long actMask = __ballot(1);
-            fullQuad = ((actMask >> (lane & 60)) & 0xFull) == 0xFull;
-            const uint32_t want = atInner ? t.cur : 0xffffffffu;
-            if (fullQuad) {
-                typedef __attribute__((address_space(1))) const void* gptr_t;
-                typedef __attribute__((address_space(3))) void* lptr_t;
-                const char* pbase = reinterpret_cast<const char*>(pairs) + (lane & 3) * 16;
-                const uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)want, 0x00, 0xf, 0xf, false);
-                const uint32_t w1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)want, 0x55, 0xf, 0xf, false);
-                const uint32_t w2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)want, 0xaa, 0xf, 0xf, false);
-                const uint32_t w3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)want, 0xff, 0xf, 0xf, false);
-                if (w0 != 0xffffffffu) __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (size_t)w0 * 64), (lptr_t)(coopSlab + 0 * 260), 16, 0, 0);
-                if (w1 != 0xffffffffu) __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (size_t)w1 * 64), (lptr_t)(coopSlab + 1 * 260), 16, 0, 0);
-                if (w2 != 0xffffffffu) __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (size_t)w2 * 64), (lptr_t)(coopSlab + 2 * 260), 16, 0, 0);
-                if (w3 != 0xffffffffu) __builtin_amdgcn_global_load_lds((gptr_t)(pbase + (size_t)w3 * 64), (lptr_t)(coopSlab + 3 * 260), 16, 0, 0);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            }
-#endif
             if (atInner) { /* ---- B: one inner node, RC:262-282 */
                 if (STATS && !t.rootStep) st.inner++;
                 t.rootStep = false;
                 phase_mark<STATS>(st, PH_INNER);
-                float4 q0, q1, q2, q3;
-#if RT_COOP_FETCH
-                if (fullQuad) {
-                    const float4* lq = reinterpret_cast<const float4*>(coopSlab + (lane & 3) * 260 + (lane >> 2) * 16);
-                    q0 = lq[0]; q1 = lq[1]; q2 = lq[2]; q3 = lq[3];
-                } else
-#endif
-                {
-                    const float4* q = reinterpret_cast<const float4*>(pairs + t.cur);
-                    q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
-                }
+                const float4* q = reinterpret_cast<const float4*>(pairs + t.cur);
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
                 float aMin[3] = {q0.x, q0.y, q0.z}, aMax[3] = {q0.w, q1.x, q1.y};
                 float bMin[3] = {q1.z, q1.w, q2.x}, bMax[3] = {q2.y, q2.z, q2.w};
                 uint32_t codeA = __float_as_uint(q3.x), codeB = __float_as_uint(q3.y);
@@ -500,14 +466,10 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
             if (t.sp == 0) t.cur = RT_CODE_NEXT_MODEL;
             else t.cur = stackBase[(--t.sp) * RT_WAVE];
         }
-        if (SUSPEND) {
-            /* lanes still here = lanes still traversing; leave together once at least half of
-             * the entrants are done (they wait outside for shading) */
-            const int active = __popcll(__ballot(1));
-            if (active * RT_SUSPEND_DEN <= entered * RT_SUSPEND_NUM) break;
-        }
-    }
-    return finished;
+        RT_TRAV_VOTE();
+    } while ((nA + nB + nC) * RT_SUSPEND_DEN > enteredNum);
+#undef RT_TRAV_VOTE
+    return t.cur == RT_CODE_DONE;
 }
 
 /* Scenes in which every model's root is a leaf (quads, small meshes built with
@@ -766,7 +728,7 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
                 if (FLAT) traverse_flat<STATS>(a, rpos, rdir, h, st);
             }
         }
-        if (inTrav && (FLAT || traverse<STATS, true>(a, rpos, rdir, stackBase, h, t, st, &s_stack[(size_t)(a.stackEntries + RT_PIXEL_FIELDS) * RT_WAVE]))) {
+        if (inTrav && (FLAT || traverse<STATS, true>(a, rpos, rdir, stackBase, h, t, st))) {
             inTrav = false;
             /* the rest of one iteration of Trace's bounce loop — RC:488-538 */
             bool endPath = false;

@@ -65,3 +65,45 @@ def test_random_scene_bit_exact(pkg, api, orc, seed):
     assert same.all(), f"seed {seed}: {int((~same.all(axis=-1)).sum())} pixels differ"
     assert ca == cb, (seed, ca, cb)
     assert viol == 0
+
+
+def crowded_scene(pkg, n_models, n_spheres, seed=7):
+    """More models than the 64-bit root-filter mask holds and more spheres than one 32-wide
+    candidate word: the kernel's overflow paths (models >= 64 visited unfiltered, second sphere
+    word) must give the reference's in-order results."""
+    rng = np.random.default_rng(seed)
+    M, T = pkg.RayTracingMaterial, pkg.Transform
+    meshes = [pkg.meshes.cube(), pkg.meshes.rounded_cube(3), pkg.meshes.quad()]
+    models = [pkg.Model(meshes[i % 3], M(flag=int(i % 4 == 3) * 2, diffuseCol=tuple(rng.uniform(0.2, 1, 3)) + (1,), ior=1.4,
+                                         emissionStrength=float(i % 9 == 0) * 3.0, emissionCol=(1, 0.9, 0.7, 1)),
+                        T(tuple(rng.uniform(-4, 4, 3) + [0, 1.5, 4]), tuple(rng.uniform(0, 360, 3)), float(rng.uniform(0.2, 0.7))))
+              for i in range(n_models)]
+    spheres = [pkg.Sphere(tuple(rng.uniform(-4, 4, 3) + [0, 1.5, 4]), float(rng.uniform(0.1, 0.5)),
+                          M(flag=int(i % 5 == 0) * 2, diffuseCol=tuple(rng.uniform(0.2, 1, 3)) + (1,), ior=1.5, smoothness=0.6,
+                            specularProbability=0.4))
+               for i in range(n_spheres)]
+    cam = pkg.Camera(T((0, 1.5, -6), (0, 0, 0)), fieldOfView=55.0)
+    settings = dict(maxBounceCount=5, numRaysPerPixel=2, divergeStrength=0.5, useSky=True, accumulate=True, bvhQuality=1)
+    return pkg.scenes.SceneDescription("crowded", 88, 48, 2, settings, cam, models, spheres)
+
+
+@pytest.mark.parametrize("n_models,n_spheres,quality", [(64, 32, 1), (65, 33, 1), (97, 70, 0), (3, 64, 1), (70, 5, 2)])
+def test_more_models_and_spheres_than_one_mask_word(pkg, api, orc, n_models, n_spheres, quality):
+    out = []
+    for lib, tr in ((api, api.create_tracer(0)), (orc, orc.create_tracer(8))):
+        sc = crowded_scene(pkg, n_models, n_spheres)
+        sc.settings["bvhQuality"] = quality   # 2 = no BVH: every root is a leaf (flat kernel variant)
+        if lib is api:
+            tr.enable_stats(True)
+        mgr = sc.make_manager(tr, lib)
+        mgr.OnEnable(renderSeed=11)
+        mgr.RenderFrames(sc.frames)
+        acc = tr.read_accumulated()
+        c = tr.counters()
+        viol = tr.phase_profile()["filter_violations"][0] if lib is api else 0
+        out.append((acc, [c[k] for k in KEYS], viol))
+        tr.close()
+    (a, ca, viol), (b, cb, _) = out
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    assert ca == cb and viol == 0
+    assert ca[KEYS.index("modelVisits")] == ca[KEYS.index("segments")] * n_models
