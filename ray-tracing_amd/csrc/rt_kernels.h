@@ -123,7 +123,8 @@ __device__ __forceinline__ rt_f2 rand_circle(uint32_t* state)
 }
 
 /* GetEnvironmentLight — RC:167-183 (UseSky checked by the caller) */
-__device__ __forceinline__ rt_f3 environment_light(const KArgs& a, rt_f3 dir)
+template <class Args>
+__device__ __forceinline__ rt_f3 environment_light(const Args& a, rt_f3 dir)
 {
     float skyGradientT = rt_pow(rt_smoothstep(0.0f, 1.0f / 0.4f, dir.y), 0.35f);
     float groundToSkyT = rt_smoothstep(-0.01f, 1.0f / 0.01f, dir.y);
@@ -542,6 +543,17 @@ __device__ __forceinline__ void resolve_hit(const KArgs& a, rt_f3 rpos, rt_f3 rd
     }
 }
 
+/* Kernel arguments that only the per-pixel bookkeeping reads (tile queue, camera, targets,
+ * sky) are fetched where they are used, through a pointer the optimiser cannot see through:
+ * read as plain `a.field` they would all be loaded once up front and then held in — and
+ * spilled from — scalar registers across the traversal and shading code. */
+__device__ __forceinline__ const RT_CAS KArgs& cold_args()
+{
+    const RT_CAS void* p = (const RT_CAS void*)__builtin_amdgcn_kernarg_segment_ptr(); /* KArgs is the only kernel argument */
+    asm volatile("" : "+s"(p));
+    return *(const RT_CAS KArgs*)p;
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -570,31 +582,28 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
     const int lane = threadIdx.x;
     uint32_t* stackBase = &s_stack[lane];
 
-    /* wave-uniform camera constants — RC:547,557-558 */
-    const rt_f3 camOrigin = rt_mul_point(a.cam, rt_v3(0.0f, 0.0f, 0.0f), 1.0f);
-    const rt_f3 camRight = rt_v3(a.cam[0], a.cam[1], a.cam[2]);
-    const rt_f3 camUp = rt_v3(a.cam[4], a.cam[5], a.cam[6]);
-    const float invNumPixelsX = rt_rcp((float)a.W); /* x / numPixels.x == x * rcp (rt_div), wave-uniform */
-    const int frameEnd = a.frame0 + a.nFrames;
-    const int nTiles = a.tilesX * a.tilesY;
-
     /* Persistent wave: the wave starts on tile blockIdx.x and, whenever lanes run out of
      * work (their pixel is finished), hands them the next unassigned pixels of its current
      * "pool" tile, pulling a fresh 8x8 tile from a global atomic queue when the pool is
      * used up.  Consecutive pool slots are neighbouring pixels, so the rays a wave holds stay
      * spatially close, but no lane idles while its tile mates finish their longer paths. */
     int poolTile = (int)blockIdx.x;
-    if (a.tileOrder && poolTile < nTiles) poolTile = (int)a.tileOrder[poolTile];
     int poolPos = 0; /* next unassigned slot of the pool tile, 64 = exhausted */
-    if ((int)blockIdx.x >= nTiles || a.nFrames <= 0) poolPos = 64;
-    bool queueEmpty = (a.nFrames <= 0);
+    bool queueEmpty;
+    {
+        const RT_CAS KArgs& c = cold_args();
+        const int nTiles = c.tilesX * c.tilesY;
+        if (c.tileOrder && poolTile < nTiles) poolTile = (int)c.tileOrder[poolTile];
+        if ((int)blockIdx.x >= nTiles || c.nFrames <= 0) poolPos = 64;
+        queueEmpty = (c.nFrames <= 0);
+    }
 
     /* per-lane pixel state */
     bool laneDone = true; /* no pixel assigned */
     /* Pixel bookkeeping that is only touched when a path starts or ends lives in LDS next to the
      * traversal stack ([field][lane], conflict free), not in VGPRs: it would otherwise be carried
      * through — and spilled around — the traversal and shading code. */
-    uint32_t* const pxu = &s_stack[(size_t)a.stackEntries * RT_WAVE + lane];
+    uint32_t* const pxu = &s_stack[(size_t)cold_args().stackEntries * RT_WAVE + lane];
     float* const pxf = reinterpret_cast<float*>(pxu);
     enum { PX_INDEX = 0, PX_LINEAR, PX_SEGSTART, PX_FRAME, PX_SAMPLE, PX_FPX, PX_FPY, PX_FPZ, PX_TIX, PX_TIY, PX_TIZ };
 #define PXU(k) pxu[(k) * RT_WAVE]
@@ -616,13 +625,14 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
         /* ---- hand pixels to idle lanes (every lane of the wave is active here) */
         unsigned long long idle = __ballot(laneDone);
         while (idle) {
+            const RT_CAS KArgs& c = cold_args();
             if (poolPos >= 64) {
                 if (queueEmpty) break;
                 int next = 0;
-                if (lane == 0) next = (int)(atomicAdd(a.tileQueue, 1ull) - a.tileQueueBase);
+                if (lane == 0) next = (int)(atomicAdd(c.tileQueue, 1ull) - c.tileQueueBase);
                 next = __builtin_amdgcn_readfirstlane(next);
-                if (next >= nTiles) { queueEmpty = true; break; }
-                poolTile = a.tileOrder ? (int)a.tileOrder[next] : next;
+                if (next >= c.tilesX * c.tilesY) { queueEmpty = true; break; }
+                poolTile = c.tileOrder ? (int)c.tileOrder[next] : next;
                 poolPos = 0;
             }
             const int rank = __popcll(idle & ((1ull << lane) - 1ull));
@@ -630,30 +640,32 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
             if (laneDone && rank < avail) {
                 phase_mark<STATS>(st, PH_REFILL);
                 const int slot = poolPos + rank;
-                const int tx = poolTile % a.tilesX, ty = poolTile / a.tilesX;
+                const int tx = poolTile % c.tilesX, ty = poolTile / c.tilesX;
                 const int x = tx * 8 + (slot & 7);
                 const int lrow = ty * 8 + (slot >> 3);
-                if (x < (int)a.W && lrow < a.localRows) {
+                if (x < (int)c.W && lrow < c.localRows) {
                     /* cyclic strips: local strip ls is global strip ls*partCount + partIndex */
-                    const int ls = lrow / a.stripRows;
-                    const int y = (ls * a.partCount + a.partIndex) * a.stripRows + (lrow - ls * a.stripRows);
+                    const int ls = lrow / c.stripRows;
+                    const int y = (ls * c.partCount + c.partIndex) * c.stripRows + (lrow - ls * c.stripRows);
                     /* RCC:15 */
-                    const float uvx = rt_div((float)(uint32_t)x, (float)a.W - 1.0f);
-                    const float uvy = rt_div((float)(uint32_t)y, (float)a.H - 1.0f);
+                    const float uvx = rt_div((float)(uint32_t)x, (float)c.W - 1.0f);
+                    const float uvy = rt_div((float)(uint32_t)y, (float)c.H - 1.0f);
                     /* RC:550-556 */
-                    const uint32_t pixelCoordX = (uint32_t)(uvx * (float)a.W);
-                    const uint32_t pixelCoordY = (uint32_t)(uvy * (float)a.H);
-                    const uint32_t pixelIndex = pixelCoordY * a.W + pixelCoordX;
-                    const rt_f3 fpl = rt_v3(uvx - 0.5f, uvy - 0.5f, 1.0f) * rt_v3(a.viewParams[0], a.viewParams[1], a.viewParams[2]);
-                    const rt_f3 focusPoint = rt_mul_point(a.cam, fpl, 1.0f);
+                    const uint32_t pixelCoordX = (uint32_t)(uvx * (float)c.W);
+                    const uint32_t pixelCoordY = (uint32_t)(uvy * (float)c.H);
+                    const uint32_t pixelIndex = pixelCoordY * c.W + pixelCoordX;
+                    const rt_f3 fpl = rt_v3(uvx - 0.5f, uvy - 0.5f, 1.0f) * rt_v3(c.viewParams[0], c.viewParams[1], c.viewParams[2]);
+                    float cam[16];
+                    for (int k = 0; k < 16; k++) cam[k] = c.cam[k];
+                    const rt_f3 focusPoint = rt_mul_point(cam, fpl, 1.0f);
                     PXU(PX_INDEX) = pixelIndex;
-                    PXU(PX_LINEAR) = (uint32_t)lrow * a.W + (uint32_t)x;
+                    PXU(PX_LINEAR) = (uint32_t)lrow * c.W + (uint32_t)x;
                     PXU(PX_SEGSTART) = segments;
-                    PXU(PX_FRAME) = (uint32_t)a.frame0;
+                    PXU(PX_FRAME) = (uint32_t)c.frame0;
                     PXU(PX_SAMPLE) = 0;
                     PXF(PX_FPX) = focusPoint.x; PXF(PX_FPY) = focusPoint.y; PXF(PX_FPZ) = focusPoint.z;
                     PXF(PX_TIX) = 0.0f; PXF(PX_TIY) = 0.0f; PXF(PX_TIZ) = 0.0f;
-                    rng = pixelIndex + (uint32_t)a.frame0 * 719393u + (uint32_t)a.seed; /* RC:552 */
+                    rng = pixelIndex + (uint32_t)c.frame0 * 719393u + (uint32_t)c.seed; /* RC:552 */
                     pathActive = false;
                     inTrav = false;
                     laneDone = false;
@@ -668,55 +680,63 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
         phase_mark<STATS>(st, PH_LOOP);
         if (!inTrav) {
             if (!pathActive) {
+                const RT_CAS KArgs& c = cold_args();
                 int sample = (int)PXU(PX_SAMPLE);
-                if (sample == a.spp) {
+                if (sample == c.spp) {
                     /* RC:581 + RCC:18-23: finish this frame of this pixel */
                     const uint32_t pixLinear = PXU(PX_LINEAR);
                     const size_t pixOff = (size_t)pixLinear * 4;
                     int frame = (int)PXU(PX_FRAME);
-                    rt_f3 col = rt_v3(PXF(PX_TIX), PXF(PX_TIY), PXF(PX_TIZ)) / (float)a.spp;
-                    if (frame == frameEnd - 1) {
+                    rt_f3 col = rt_v3(PXF(PX_TIX), PXF(PX_TIY), PXF(PX_TIZ)) / (float)c.spp;
+                    if (frame == (c.frame0 + c.nFrames) - 1) {
                         float4 o = make_float4(col.x, col.y, col.z, 1.0f);
-                        *reinterpret_cast<float4*>(a.frameRender + pixOff) = o;
+                        *reinterpret_cast<float4*>(c.frameRender + pixOff) = o;
                     }
-                    if (a.accumulate) {
-                        float4 acc = *reinterpret_cast<float4*>(a.accumulated + pixOff);
+                    if (c.accumulate) {
+                        float4 acc = *reinterpret_cast<float4*>(c.accumulated + pixOff);
                         acc.x += col.x;
                         acc.y += col.y;
                         acc.z += col.z;
                         acc.w += 1.0f;
-                        *reinterpret_cast<float4*>(a.accumulated + pixOff) = acc;
+                        *reinterpret_cast<float4*>(c.accumulated + pixOff) = acc;
                     }
                     frame++;
-                    if (frame == frameEnd) {
+                    if (frame == (c.frame0 + c.nFrames)) {
                         laneDone = true;
-                        if (a.tileCost) { /* longest serial chain of this tile's pixels: next frame's queue order */
-                            const uint32_t prow = pixLinear / a.W, pcol = pixLinear - prow * a.W;
-                            atomicMax(a.tileCost + (prow >> 3) * (uint32_t)a.tilesX + (pcol >> 3), (segments - PXU(PX_SEGSTART)) / (uint32_t)a.nFrames);
+                        if (c.tileCost) { /* longest serial chain of this tile's pixels: next frame's queue order */
+                            const uint32_t prow = pixLinear / c.W, pcol = pixLinear - prow * c.W;
+                            atomicMax(c.tileCost + (prow >> 3) * (uint32_t)c.tilesX + (pcol >> 3), (segments - PXU(PX_SEGSTART)) / (uint32_t)c.nFrames);
                         }
                     } else {
-                        rng = PXU(PX_INDEX) + (uint32_t)frame * 719393u + (uint32_t)a.seed;
+                        rng = PXU(PX_INDEX) + (uint32_t)frame * 719393u + (uint32_t)c.seed;
                         sample = 0;
                         PXU(PX_FRAME) = (uint32_t)frame;
                         PXU(PX_SAMPLE) = 0;
                         PXF(PX_TIX) = 0.0f; PXF(PX_TIY) = 0.0f; PXF(PX_TIZ) = 0.0f;
                     }
                 }
-                if (!laneDone && sample < a.spp) {
+                if (!laneDone && sample < c.spp) {
                     /* RC:565-576: next camera ray of this pixel */
                     phase_mark<STATS>(st, PH_RAYGEN);
+                    /* camera constants — RC:547,557-558 */
+                    float cam[16];
+                    for (int k = 0; k < 16; k++) cam[k] = c.cam[k];
+                    const rt_f3 camOrigin = rt_mul_point(cam, rt_v3(0.0f, 0.0f, 0.0f), 1.0f);
+                    const rt_f3 camRight = rt_v3(cam[0], cam[1], cam[2]);
+                    const rt_f3 camUp = rt_v3(cam[4], cam[5], cam[6]);
+                    const float invNumPixelsX = rt_rcp((float)c.W); /* x / numPixels.x == x * rcp (rt_div) */
                     rt_f2 dj = rand_circle(&rng);
-                    rt_f3 rayOrigin = camOrigin + camRight * (dj.x * a.defocus * invNumPixelsX) + camUp * (dj.y * a.defocus * invNumPixelsX);
+                    rt_f3 rayOrigin = camOrigin + camRight * (dj.x * c.defocus * invNumPixelsX) + camUp * (dj.y * c.defocus * invNumPixelsX);
                     rt_f2 jj = rand_circle(&rng);
                     const rt_f3 focusPoint = rt_v3(PXF(PX_FPX), PXF(PX_FPY), PXF(PX_FPZ));
-                    rt_f3 jfp = focusPoint + camRight * (jj.x * a.diverge * invNumPixelsX) + camUp * (jj.y * a.diverge * invNumPixelsX);
+                    rt_f3 jfp = focusPoint + camRight * (jj.x * c.diverge * invNumPixelsX) + camUp * (jj.y * c.diverge * invNumPixelsX);
                     rpos = rayOrigin;
                     rdir = rt_normalize(jfp - rayOrigin);
                     transmittance = rt_v3s(1.0f);
                     pathLight = rt_v3s(0.0f);
                     bounce = 0;
                     PXU(PX_SAMPLE) = (uint32_t)(sample + 1);
-                    if (a.maxBounce >= 0) pathActive = true;                /* RC:485: the loop runs for i = 0 */
+                    if (c.maxBounce >= 0) pathActive = true;                /* RC:485: the loop runs for i = 0 */
                     else { PXF(PX_TIX) = PXF(PX_TIX) + 0.0f; PXF(PX_TIY) = PXF(PX_TIY) + 0.0f; PXF(PX_TIZ) = PXF(PX_TIZ) + 0.0f; } /* Trace returned 0 (RC:578) */
                 }
             }
@@ -734,7 +754,8 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
             bool endPath = false;
             if (h.obj < 0) {
                 phase_mark<STATS>(st, PH_SKY);
-                if (a.useSky) pathLight = pathLight + transmittance * environment_light(a, rdir);
+                const RT_CAS KArgs& c = cold_args();
+                if (c.useSky) pathLight = pathLight + transmittance * environment_light(c, rdir);
                 endPath = true;
             } else {
                 /* resolve the winner: position, normal, material */
