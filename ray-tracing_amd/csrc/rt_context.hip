@@ -758,6 +758,10 @@ static void fill_args(RtContext* ctx, int frame0, int nFrames, KArgs& a)
     memcpy(a.dirToSun, p.dirToSun, 12);
     memcpy(a.viewParams, p.viewParams, 12);
     memcpy(a.cam, p.camLocalToWorld, 64);
+    a.rcpWm1 = rt_rcp((float)a.W - 1.0f);
+    a.rcpHm1 = rt_rcp((float)a.H - 1.0f);
+    a.rcpW = rt_rcp((float)a.W);
+    a.rcpSpp = rt_rcp((float)a.spp);
     a.counters = ctx->dCounters;
 }
 

@@ -107,6 +107,11 @@ struct KArgs {
     float defocus, diverge, sunFocus, sunIntensity;
     float sunColour[3], dirToSun[3], viewParams[3];
     float cam[16];
+    /* reciprocals of launch constants, computed on the host with the same correctly rounded fp32
+     * divide the device would use (x / c == x * rcp(c), include/rt_math.h rt_div) */
+    float rcpWm1, rcpHm1;        /* 1 / (Resolution - 1)  — RCC:15 */
+    float rcpW;                  /* 1 / numPixels.x       — RC:567,572 */
+    float rcpSpp;                /* 1 / NumRaysPerPixel   — RC:581 */
     /* counters: RT_COUNTER_SLOTS x RT_COUNTER_FIELDS u64 */
     unsigned long long* counters;
     /* persistent waves: global tile queue (monotonic; this launch's tiles start at tileQueueBase) */

@@ -587,14 +587,30 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
      * "pool" tile, pulling a fresh 8x8 tile from a global atomic queue when the pool is
      * used up.  Consecutive pool slots are neighbouring pixels, so the rays a wave holds stay
      * spatially close, but no lane idles while its tile mates finish their longer paths. */
-    int poolTile = (int)blockIdx.x;
+    int poolX0 = 0, poolRow0 = 0, poolY0 = 0; /* pool tile: first column, first local row, first GLOBAL row */
     int poolPos = 0; /* next unassigned slot of the pool tile, 64 = exhausted */
     bool queueEmpty;
+    /* wave-uniform, once per tile: every row of an 8-row tile lies in one strip (stripRows % 8 == 0);
+     * cyclic strips: local strip ls is global strip ls*partCount + partIndex */
+#define RT_SET_POOL(c, tile)                                                                              \
+    do {                                                                                                  \
+        const int ty_ = (tile) / (c).tilesX;                                                              \
+        poolX0 = ((tile) - ty_ * (c).tilesX) * 8;                                                         \
+        poolRow0 = ty_ * 8;                                                                               \
+        const int ls_ = poolRow0 / (c).stripRows;                                                         \
+        poolY0 = (ls_ * (c).partCount + (c).partIndex) * (c).stripRows + (poolRow0 - ls_ * (c).stripRows); \
+        poolPos = 0;                                                                                      \
+    } while (0)
     {
         const RT_CAS KArgs& c = cold_args();
         const int nTiles = c.tilesX * c.tilesY;
-        if (c.tileOrder && poolTile < nTiles) poolTile = (int)c.tileOrder[poolTile];
-        if ((int)blockIdx.x >= nTiles || c.nFrames <= 0) poolPos = 64;
+        int tile = (int)blockIdx.x;
+        if (tile < nTiles && c.nFrames > 0) {
+            if (c.tileOrder) tile = (int)c.tileOrder[tile];
+            RT_SET_POOL(c, tile);
+        } else {
+            poolPos = 64;
+        }
         queueEmpty = (c.nFrames <= 0);
     }
 
@@ -632,24 +648,21 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
                 if (lane == 0) next = (int)(atomicAdd(c.tileQueue, 1ull) - c.tileQueueBase);
                 next = __builtin_amdgcn_readfirstlane(next);
                 if (next >= c.tilesX * c.tilesY) { queueEmpty = true; break; }
-                poolTile = c.tileOrder ? (int)c.tileOrder[next] : next;
-                poolPos = 0;
+                if (c.tileOrder) next = (int)c.tileOrder[next];
+                RT_SET_POOL(c, next);
             }
             const int rank = __popcll(idle & ((1ull << lane) - 1ull));
             const int avail = 64 - poolPos;
             if (laneDone && rank < avail) {
                 phase_mark<STATS>(st, PH_REFILL);
                 const int slot = poolPos + rank;
-                const int tx = poolTile % c.tilesX, ty = poolTile / c.tilesX;
-                const int x = tx * 8 + (slot & 7);
-                const int lrow = ty * 8 + (slot >> 3);
+                const int x = poolX0 + (slot & 7);
+                const int lrow = poolRow0 + (slot >> 3);
                 if (x < (int)c.W && lrow < c.localRows) {
-                    /* cyclic strips: local strip ls is global strip ls*partCount + partIndex */
-                    const int ls = lrow / c.stripRows;
-                    const int y = (ls * c.partCount + c.partIndex) * c.stripRows + (lrow - ls * c.stripRows);
-                    /* RCC:15 */
-                    const float uvx = rt_div((float)(uint32_t)x, (float)c.W - 1.0f);
-                    const float uvy = rt_div((float)(uint32_t)y, (float)c.H - 1.0f);
+                    const int y = poolY0 + (slot >> 3);
+                    /* RCC:15: id.xy / (Resolution - 1.0) */
+                    const float uvx = (float)(uint32_t)x * c.rcpWm1;
+                    const float uvy = (float)(uint32_t)y * c.rcpHm1;
                     /* RC:550-556 */
                     const uint32_t pixelCoordX = (uint32_t)(uvx * (float)c.W);
                     const uint32_t pixelCoordY = (uint32_t)(uvy * (float)c.H);
@@ -687,7 +700,7 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
                     const uint32_t pixLinear = PXU(PX_LINEAR);
                     const size_t pixOff = (size_t)pixLinear * 4;
                     int frame = (int)PXU(PX_FRAME);
-                    rt_f3 col = rt_v3(PXF(PX_TIX), PXF(PX_TIY), PXF(PX_TIZ)) / (float)c.spp;
+                    rt_f3 col = rt_v3(PXF(PX_TIX), PXF(PX_TIY), PXF(PX_TIZ)) * c.rcpSpp; /* / NumRaysPerPixel */
                     if (frame == (c.frame0 + c.nFrames) - 1) {
                         float4 o = make_float4(col.x, col.y, col.z, 1.0f);
                         *reinterpret_cast<float4*>(c.frameRender + pixOff) = o;
@@ -724,7 +737,7 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
                     const rt_f3 camOrigin = rt_mul_point(cam, rt_v3(0.0f, 0.0f, 0.0f), 1.0f);
                     const rt_f3 camRight = rt_v3(cam[0], cam[1], cam[2]);
                     const rt_f3 camUp = rt_v3(cam[4], cam[5], cam[6]);
-                    const float invNumPixelsX = rt_rcp((float)c.W); /* x / numPixels.x == x * rcp (rt_div) */
+                    const float invNumPixelsX = c.rcpW; /* x / numPixels.x */
                     rt_f2 dj = rand_circle(&rng);
                     rt_f3 rayOrigin = camOrigin + camRight * (dj.x * c.defocus * invNumPixelsX) + camUp * (dj.y * c.defocus * invNumPixelsX);
                     rt_f2 jj = rand_circle(&rng);
@@ -818,6 +831,9 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
         } /* !laneDone */
     }
 
+#undef RT_SET_POOL
+#undef PXU
+#undef PXF
     /* exact work counters: one set of atomics per wave, spread over slots */
     uint32_t segSum = wave_sum(segments);
     unsigned long long* slot = a.counters + (size_t)(blockIdx.x % RT_COUNTER_SLOTS) * RT_COUNTER_FIELDS;
