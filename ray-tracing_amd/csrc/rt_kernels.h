@@ -106,9 +106,15 @@ __device__ __forceinline__ float rand_normal(uint32_t* state)
 }
 __device__ __forceinline__ rt_f3 rand_direction(uint32_t* state)
 {
-    float x = rand_normal(state);
-    float y = rand_normal(state);
-    float z = rand_normal(state);
+    /* x, y, z in draw order, one after the other (a rolled loop: the three independent
+     * log/cos/sqrt chains would otherwise be interleaved and triple the live registers) */
+    float x = 0.0f, y = 0.0f, z = 0.0f;
+#pragma clang loop unroll(disable)
+    for (int i = 0; i < 3; i++) {
+        x = y;
+        y = z;
+        z = rand_normal(state);
+    }
     return rt_normalize(rt_v3(x, y, z));
 }
 /* RandomPointInCircle — RC:159-164 (PI = 3.1415, RC:2) */

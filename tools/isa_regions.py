@@ -3,13 +3,25 @@ belongs to the last rt_kernels.h line seen before it).  Needs an asm built with 
 usage: python tools/isa_regions.py <file.s> <mangled kernel name>"""
 import collections, re, sys
 
-REGIONS = [  # (name, first line, last line) in rt_kernels.h
-    ("rand/sky/optics helpers", 104, 186), ("tri_test", 188, 216), ("begin: spheres", 236, 290), ("begin: root filter", 291, 349),
-    ("trav: vote", 365, 387), ("trav A: next model", 388, 415), ("trav B: inner", 416, 481), ("trav C: leaf", 482, 502),
-    ("trav: suspend check", 503, 511), ("resolve_hit", 561, 581), ("prologue", 604, 652), ("refill", 653, 704),
-    ("frame end / accumulate", 705, 742), ("raygen", 743, 760), ("begin call", 761, 768), ("sky", 769, 777),
-    ("shade: common", 778, 792), ("shade: glass", 793, 808), ("shade: opaque", 809, 817), ("roulette/end path", 818, 836),
-    ("epilogue", 837, 866)]
+import os
+ANCHORS = [  # (region name, text that starts it in rt_kernels.h); a region runs to the next anchor
+    ("rand/sky/optics helpers", "float rand_normal(uint32_t* state)"), ("tri_test", "void tri_test("),
+    ("begin: spheres", "void begin_intersect("), ("begin: root filter", "Root filter, in lockstep"),
+    ("trav: entry vote", "bool traverse("), ("trav A: next model", "---- A: next model"), ("trav B: inner", "---- B: one inner node"),
+    ("trav C: leaf", "---- C: one leaf"), ("trav: bottom vote", "        RT_TRAV_VOTE();\n    } while"), ("traverse_flat", "void traverse_flat("),
+    ("resolve_hit", "void resolve_hit("), ("cold_args/wave_sum", "const RT_CAS KArgs& cold_args()"), ("prologue", "void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kernel("),
+    ("refill", "---- hand pixels to idle lanes"), ("frame end / accumulate", "phase_mark<STATS>(st, PH_LOOP)"), ("raygen", "next camera ray of this pixel"),
+    ("begin call", "phase_mark<STATS>(st, PH_SPHERES)"), ("sky", "the rest of one iteration of Trace's bounce loop"),
+    ("shade: common", "resolve the winner"), ("shade: glass", "phase_mark<STATS>(st, PH_GLASS)"),
+    ("shade: opaque", "bool isSpecular = mat.specularProbability >= uSpec"), ("roulette/end path", "RC:535-538 Russian roulette"),
+    ("epilogue", "exact work counters"), ("(other kernels)", "---- test hooks (rt_debug_*)")]
+src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ray-tracing_amd", "csrc", "rt_kernels.h")).read()
+starts = []
+for name, text in ANCHORS:
+    assert src.count(text) == 1, (name, src.count(text))
+    starts.append((src[:src.index(text)].count("\n") + 1, name))
+starts.sort()
+REGIONS = [(n, a, (starts[k + 1][0] - 1) if k + 1 < len(starts) else 10**9) for k, (a, n) in enumerate(starts)]
 
 s = open(sys.argv[1]).read()
 i = s.index(sys.argv[2] + ":")
