@@ -42,7 +42,8 @@ struct RtContext {
     float* boundAccum = nullptr;
 
     /* scene (device) */
-    float* dSpheres = nullptr;
+    float* dSpheres = nullptr; /* nSpheres x (c, r*r), then nSpheres x (c, |c|^2 - r*r) */
+    float sphereBound = 0;     /* max over spheres of |c|^2 + r*r, rounded up */
     DMaterial* dMaterials = nullptr;
     DModel* dModels = nullptr;
     DPair* dPairs = nullptr;
@@ -288,6 +289,27 @@ int rt_get_render_targets(RtContext* ctx, void** d_frame, void** d_accum)
 } /* extern "C" */
 
 /* ---------------------------------------------------------------- scene */
+/* Device sphere records.  First the exact one the reference's arithmetic reads — centre and
+ * radius*radius (RC:299, same fp32 multiply) — then, for all spheres again, the record of the
+ * conservative discriminant pre-test in begin_intersect: centre and |c|^2 - r*r (rounded from
+ * double).  *bound = max_k(|c_k|^2 + r_k^2), rounded up: it scales the pre-test's error margin. */
+static void pack_spheres(const RtSphere* spheres, int n, std::vector<float>& out, float* bound)
+{
+    out.assign((size_t)n * 8, 0.0f);
+    double maxM = 0;
+    for (int i = 0; i < n; i++) {
+        const float* c = spheres[i].centre;
+        const float r2 = spheres[i].radius * spheres[i].radius;
+        memcpy(&out[4 * (size_t)i], c, 12);
+        out[4 * (size_t)i + 3] = r2;
+        const double cc = (double)c[0] * c[0] + (double)c[1] * c[1] + (double)c[2] * c[2];
+        memcpy(&out[4 * ((size_t)n + i)], c, 12);
+        out[4 * ((size_t)n + i) + 3] = (float)(cc - (double)r2);
+        if (cc + (double)r2 > maxM) maxM = cc + (double)r2;
+    }
+    *bound = (float)(maxM * 1.000001);
+}
+
 static void pack_material(const RtMaterial& m, DMaterial& d)
 {
     memset(&d, 0, sizeof(d));
@@ -591,13 +613,11 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
         memcpy(dnorms[i].n + 6, t.normC, 12);
     }
 
-    std::vector<float> sph((size_t)n_spheres * 4);
+    std::vector<float> sph;
+    float sphereBound = 0;
+    pack_spheres(spheres, n_spheres, sph, &sphereBound);
     std::vector<DMaterial> mats((size_t)n_spheres + n_models);
-    for (int i = 0; i < n_spheres; i++) {
-        memcpy(&sph[4 * i], spheres[i].centre, 12);
-        sph[4 * i + 3] = spheres[i].radius * spheres[i].radius; /* RC:299 */
-        pack_material(spheres[i].material, mats[i]);
-    }
+    for (int i = 0; i < n_spheres; i++) pack_material(spheres[i].material, mats[i]);
     std::vector<DModel> dmodels(n_models);
     for (int i = 0; i < n_models; i++) {
         pack_model(models[i], rootCodes[i], dmodels[i]);
@@ -619,6 +639,7 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
     if ((rc = upload_vec(ctx, &ctx->dBigLeaves, sb.bigLeaves.data(), sb.bigLeaves.size()))) return rc;
     if ((rc = upload_vec(ctx, &ctx->dFilters, filters.data(), filters.size()))) return rc;
     ctx->filterMaxOrigin = maxOrigin;
+    ctx->sphereBound = sphereBound;
     ctx->hRootChildren = rootChildren;
     ctx->hSpheres.assign(spheres, spheres + n_spheres);
     ctx->nSpheres = n_spheres;
@@ -668,13 +689,10 @@ int rt_update_spheres(RtContext* ctx, const RtSphere* spheres, int n_spheres)
     if (!ctx->haveScene) return fail(ctx, RT_ERR_STATE, "rt_update_spheres before rt_upload_scene");
     if (n_spheres != ctx->nSpheres || (n_spheres && !spheres)) return fail(ctx, RT_ERR_INVALID_ARG, "rt_update_spheres: sphere count changed");
     if (n_spheres == 0) return RT_OK;
-    std::vector<float> sph((size_t)n_spheres * 4);
+    std::vector<float> sph;
+    pack_spheres(spheres, n_spheres, sph, &ctx->sphereBound);
     std::vector<DMaterial> mats(n_spheres);
-    for (int i = 0; i < n_spheres; i++) {
-        memcpy(&sph[4 * i], spheres[i].centre, 12);
-        sph[4 * i + 3] = spheres[i].radius * spheres[i].radius;
-        pack_material(spheres[i].material, mats[i]);
-    }
+    for (int i = 0; i < n_spheres; i++) pack_material(spheres[i].material, mats[i]);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(ctx->dSpheres, sph.data(), sph.size() * 4, hipMemcpyHostToDevice));
@@ -722,6 +740,8 @@ static void fill_args(RtContext* ctx, int frame0, int nFrames, KArgs& a)
 {
     memset(&a, 0, sizeof(a));
     a.spheres = ctx->dSpheres;
+    a.sphereQuick = ctx->dSpheres + 4 * (size_t)ctx->nSpheres;
+    a.sphereBound = ctx->sphereBound;
     a.materials = ctx->dMaterials;
     a.models = ctx->dModels;
     a.pairs = ctx->dPairs;

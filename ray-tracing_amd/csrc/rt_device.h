@@ -85,6 +85,8 @@ struct DMaterial {
 struct KArgs {
     /* scene */
     const float* spheres;        /* nSpheres x (cx, cy, cz, r*r) */
+    const float* sphereQuick;    /* nSpheres x (cx, cy, cz, |c|^2 - r*r): conservative pre-test */
+    float sphereBound;           /* max_k(|c_k|^2 + r_k^2): scales the pre-test's error margin */
     const DMaterial* materials;  /* [0,nSpheres) spheres, then models */
     const DModel* models;
     const DPair* pairs;

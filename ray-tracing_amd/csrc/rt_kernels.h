@@ -244,25 +244,49 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
     h.u = h.v = h.det = 0.0f;
     h.backface = false;
 
-    /* RaySphere — RC:289-332, in two phases so the expensive part (sqrt + two divides)
-     * runs only for (ray, sphere) pairs whose discriminant is non-negative:
-     *   phase 1, wave-uniform loop, sphere data in SGPRs: discriminant only -> per-lane bitmask;
+    /* RaySphere — RC:289-332, in two phases so that the reference's arithmetic (and its sqrt +
+     * divides) runs only for (ray, sphere) pairs that can be hits:
+     *   phase 1, wave-uniform loop, sphere data in SGPRs: a CONSERVATIVE sign test of the
+     *   discriminant -> per-lane bitmask.  It evaluates D = ((o-c).d)^2 - (d.d)(|o-c|^2 - r^2)
+     *   in expanded form, (o.d - c.d)^2 - (d.d)(|o|^2 - 2 o.c + (|c|^2 - r^2)), with the per-ray
+     *   terms hoisted and fused multiply-adds (half the operations of the reference's form), and
+     *   rejects only when D' < -margin.  Rounding-error bounds (u = 2^-24, S = |o| + |c|):
+     *       reference form  |disc/4 - D| <= u (d.d) (21 |o-c|^2 + 11 r^2)
+     *       expanded form   |D'    - D| <= u (d.d) (22 S^2 + 8 r^2)
+     *   so margin = 2^-17 (d.d) (|o|^2 + max_k(|c_k|^2 + r_k^2)) >= 128 u (d.d)(|o|^2 + |c|^2 + r^2)
+     *   covers their sum (S^2 <= 2|o|^2 + 2|c|^2) with 1.5x to spare: a rejected pair has a
+     *   negative discriminant in the reference's arithmetic too.  The comparison is written so
+     *   that NaN / overflow keeps the candidate.  The stats build audits this (must count 0).
      *   phase 2, per lane: walk the set bits in increasing sphere order (strict '<' keeps
-     *   the first of equal hits, like the reference's in-order loop) and redo the same
-     *   fp32 operations for that sphere, then the roots.
+     *   the first of equal hits, like the reference's in-order loop) and do the reference's
+     *   fp32 operations for that sphere: discriminant, then the roots.
      * 4th float of a sphere record is radius*radius, computed on upload with the same fp32 multiply. */
     const RT_CAS float* sph = (const RT_CAS float*)a.spheres;
+    const RT_CAS float* sphq = (const RT_CAS float*)a.sphereQuick;
     const float qa = rt_dot(rdir, rdir);
+    const float od = __builtin_fmaf(rpos.x, rdir.x, __builtin_fmaf(rpos.y, rdir.y, rpos.z * rdir.z));
+    const float oo = __builtin_fmaf(rpos.x, rpos.x, __builtin_fmaf(rpos.y, rpos.y, rpos.z * rpos.z));
+    const float negMargin = -(7.62939453125e-06f * qa * (oo + a.sphereBound)); /* 2^-17 */
     for (int base = 0; base < a.nSpheres; base += 32) {
         const int n = (a.nSpheres - base) < 32 ? (a.nSpheres - base) : 32;
         uint32_t cand = 0;
         for (int k = 0; k < n; k++) {
             const int s = base + k;
-            rt_f3 off = rpos - rt_v3(sph[4 * s + 0], sph[4 * s + 1], sph[4 * s + 2]);
-            float qb = 2 * rt_dot(off, rdir);
-            float qc = rt_dot(off, off) - sph[4 * s + 3];
-            float disc = qb * qb - 4 * qa * qc;
-            cand |= (disc >= 0 ? 1u : 0u) << k;
+            const float cx = sphq[4 * s + 0], cy = sphq[4 * s + 1], cz = sphq[4 * s + 2];
+            const float cd = __builtin_fmaf(cx, rdir.x, __builtin_fmaf(cy, rdir.y, cz * rdir.z));
+            const float co = __builtin_fmaf(cx, rpos.x, __builtin_fmaf(cy, rpos.y, cz * rpos.z));
+            const float b = od - cd;
+            const float ct = __builtin_fmaf(-2.0f, co, oo) + sphq[4 * s + 3];
+            const float dq = __builtin_fmaf(b, b, -(qa * ct));
+            const bool keep = !(dq < negMargin);
+            if (STATS) { /* audit against the reference's discriminant */
+                rt_f3 off = rpos - rt_v3(sph[4 * s + 0], sph[4 * s + 1], sph[4 * s + 2]);
+                float qb = 2 * rt_dot(off, rdir);
+                float qc = rt_dot(off, off) - sph[4 * s + 3];
+                float disc = qb * qb - 4 * qa * qc;
+                if (disc >= 0 && !keep) st.filterViolations++;
+            }
+            cand |= (keep ? 1u : 0u) << k;
         }
         while (cand) {
             phase_mark<STATS>(st, PH_SPHERE_ROOTS);
@@ -274,6 +298,7 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
             float qb = 2 * rt_dot(off, rdir);
             float qc = rt_dot(off, off) - sp.w;
             float disc = qb * qb - 4 * qa * qc;
+            if (!(disc >= 0)) continue; /* RC:304: a false positive of phase 1 ends here */
             float sq = rt_sqrt(disc);
             const float inv2a = rt_rcp(2 * qa); /* both roots share the reciprocal (rt_div) */
             float dstNear = rt_max(0.0f, (-qb - sq) * inv2a);

@@ -9,7 +9,7 @@ ANCHORS = [  # (region name, text that starts it in rt_kernels.h); a region runs
     ("begin: spheres", "void begin_intersect("), ("begin: root filter", "Root filter, in lockstep"),
     ("trav: entry vote", "bool traverse("), ("trav A: next model", "---- A: next model"), ("trav B: inner", "---- B: one inner node"),
     ("trav C: leaf", "---- C: one leaf"), ("trav: bottom vote", "        RT_TRAV_VOTE();\n    } while"), ("traverse_flat", "void traverse_flat("),
-    ("resolve_hit", "void resolve_hit("), ("cold_args/wave_sum", "const RT_CAS KArgs& cold_args()"), ("prologue", "void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kernel("),
+    ("resolve_hit", "void resolve_hit("), ("cold_args/wave_sum", "const RT_CAS KArgs& cold_args()"), ("prologue", ") rt_trace_kernel(const KArgs a)"),
     ("refill", "---- hand pixels to idle lanes"), ("frame end / accumulate", "phase_mark<STATS>(st, PH_LOOP)"), ("raygen", "next camera ray of this pixel"),
     ("begin call", "phase_mark<STATS>(st, PH_SPHERES)"), ("sky", "the rest of one iteration of Trace's bounce loop"),
     ("shade: common", "resolve the winner"), ("shade: glass", "phase_mark<STATS>(st, PH_GLASS)"),
