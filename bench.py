@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, help="scene id (default 2 = the headline workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched", action="store_true", help="skip the informational rt_render_frames(K) pass (profile runs)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     args = ap.parse_args()
 
@@ -124,7 +125,8 @@ def main():
         torch.cuda.synchronize()
 
     # ---- warmup
-    mgr.RenderFrames(args.warmup)
+    for _ in range(args.warmup):
+        mgr.RenderFrame()
     barrier()
     first_frame = tracer.frame()
 
@@ -155,15 +157,49 @@ def main():
 
     # ---- informational: the same K frames through the batched API (rt_render_frames: up to 16
     # frames per launch, each pixel runs its frames back to back; identical final buffers)
-    mgr.numAccumulatedFrames = first_frame
-    mgr.SetShaderParams()
-    tracer.reset_counters()
-    barrier()
-    b0 = time.perf_counter()
-    tracer.render_frames(args.steps)
-    barrier()
-    batched_elapsed = time.perf_counter() - b0
-    batched_segments = tracer.counters()["segments"]
+    batched = None
+    if not args.no_batched:
+        mgr.numAccumulatedFrames = first_frame
+        mgr.SetShaderParams()
+        tracer.reset_counters()
+        barrier()
+        b0 = time.perf_counter()
+        tracer.render_frames(args.steps)
+        barrier()
+        batched_elapsed = time.perf_counter() - b0
+        batched = {"what": "rt_render_frames(K): frames fused up to 16 per launch (this rank)",
+                   "value": tracer.counters()["segments"] / batched_elapsed / 1e6, "unit": "Mrays/s",
+                   "ms_per_frame": batched_elapsed / args.steps * 1e3}
+
+    # ---- roofline pass (rank 0): the timed pass above launches every frame as two kernels on two
+    # streams that overlap in time, so "duration of one launch" is not defined there.  The same K
+    # frames are rendered once more by a context restricted to ONE kernel per frame on one stream
+    # (RT_TWO_STREAMS=0): HIP events around those K launches give the kernel's average launch
+    # duration, the figure rocprofv3 --kernel-trace reports for the same mode (profiles/).
+    single_ms = None
+    if rank == 0:
+        if os.environ.get("RT_TWO_STREAMS") == "0":
+            single_ms = timed["gpuMs"] / args.steps
+        else:
+            os.environ["RT_TWO_STREAMS"] = "0"
+            t1s = api.create_tracer(dev_index)
+            del os.environ["RT_TWO_STREAMS"]
+            if tiled:
+                t1s.set_partition(pkg.dist.STRIP_ROWS, rank, world)
+            m1 = scene.make_manager(t1s, api, W, H)
+            m1.OnEnable(renderSeed=1)
+            for _ in range(args.warmup):
+                m1.RenderFrame()
+            t1s.synchronize()
+            t1s.reset_counters()
+            t1s.timer_begin()
+            for _ in range(args.steps):
+                t1s.render_frame()
+            t1s.timer_end()
+            one = t1s.counters()
+            assert one["segments"] == segments, (one["segments"], segments)
+            single_ms = one["gpuMs"] / args.steps
+            t1s.close()
 
     # ---- readback: the one collective of the multi-GPU path
     gather_ms = None
@@ -191,7 +227,7 @@ def main():
         # roofline of the dominant (only) kernel, rt_trace_kernel: algorithmic bytes of THIS
         # rank's launch / its average duration from HIP events on the launch stream
         my_bytes = pkg.abi.algorithmic_bytes(stats, n_models, n_spheres) / args.steps
-        my_ms = timed["gpuMs"] / args.steps
+        my_ms = single_ms
         achieved = my_bytes / (my_ms * 1e-3) / 1e9
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -224,9 +260,9 @@ def main():
             "resolution": [W, H],
             "kernel_ms_per_step": kernel_ms_max / args.steps,
             "gather_ms": gather_ms,
-            "batched_api": {"what": "rt_render_frames(K): frames fused up to 16 per launch (this rank)",
-                            "value": batched_segments / batched_elapsed / 1e6, "unit": "Mrays/s",
-                            "ms_per_frame": batched_elapsed / args.steps * 1e3},
+            "launches": "2 kernels per frame on 2 streams (disjoint tile halves, overlapping in time)"
+                        if os.environ.get("RT_TWO_STREAMS") != "0" else "1 kernel per frame",
+            "batched_api": batched,
             "parity": "bit-identical to oracle/ on tests/ (pytest -m gpu); max rel err 0",
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -234,7 +270,8 @@ def main():
                 "kernel": "rt_trace_kernel<false>",
                 "algorithmic_bytes_per_launch": my_bytes, "avg_launch_ms": my_ms,
                 "note": "algorithmic bytes = the reference loop's loads for the counted work (SURVEY.md 8(d)); "
-                        "the scene is cache/SGPR resident, so frac can exceed what HBM itself delivers",
+                        "the scene is cache/SGPR resident, so frac can exceed what HBM itself delivers. "
+                        "avg_launch_ms: one kernel per frame on one stream (RT_TWO_STREAMS=0 pass), HIP events",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

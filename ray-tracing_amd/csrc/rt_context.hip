@@ -29,6 +29,14 @@ struct RtContext {
     int device = 0;
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
+    /* Second render stream (see launch_frames): while the context runs on its own stream, every
+     * frame is launched as two kernels over disjoint halves of the tiles, one per stream, so that
+     * the drain of one kernel overlaps the other instead of idling the chip. */
+    hipStream_t sideStream = nullptr;
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    bool sideDirty = false; /* sideStream holds work the main stream has not been ordered after */
+    bool needFork = true;   /* the main stream holds non-render work the side stream must follow */
+    bool twoStreams = true; /* RT_TWO_STREAMS=0: one kernel per launch on the main stream */
     char err[512] = {0};
 
     /* image */
@@ -69,8 +77,8 @@ struct RtContext {
 
     /* counters */
     unsigned long long* dCounters = nullptr;
-    unsigned long long* dTileQueue = nullptr; /* monotonic tile counter of the persistent kernel */
-    unsigned long long tileQueueNext = 0;     /* value the counter will have when the next launch starts */
+    unsigned long long* dTileQueue = nullptr;      /* monotonic tile counters of the persistent kernel, one per render stream */
+    unsigned long long tileQueueNext[2] = {0, 0};  /* value each counter will have when that stream's next launch starts */
     uint32_t* dTileCost = nullptr;  /* per tile: longest pixel chain (segments per frame) seen so far */
     uint32_t* dTileOrder = nullptr; /* queue position -> tile, longest chain first */
     int orderTiles = 0;             /* tiles the two arrays are sized for; 0 = none */
@@ -109,6 +117,19 @@ static int fail(RtContext* ctx, int status, const char* fmt, ...)
         if (e_ != hipSuccess)                                                                       \
             return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
+
+/* The main stream, ordered after everything the second render stream has been given.  Every
+ * use of the stream other than a render launch goes through here. */
+static hipStream_t joined(RtContext* ctx)
+{
+    if (ctx->sideDirty) {
+        hipEventRecord(ctx->evJoin, ctx->sideStream);
+        hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0);
+        ctx->sideDirty = false;
+    }
+    ctx->needFork = true;
+    return ctx->stream;
+}
 
 static int local_rows_for(int H, int stripRows, int partIndex, int partCount)
 {
@@ -159,10 +180,19 @@ int rt_create(int device_id, RtContext** out)
         ctx->stream = ctx->ownStream;
         HIP_TRY(ctx, hipMalloc(&ctx->dCounters, sizeof(unsigned long long) * RT_COUNTER_SLOTS * RT_COUNTER_FIELDS));
         HIP_TRY(ctx, hipMemset(ctx->dCounters, 0, sizeof(unsigned long long) * RT_COUNTER_SLOTS * RT_COUNTER_FIELDS));
-        HIP_TRY(ctx, hipMalloc(&ctx->dTileQueue, sizeof(unsigned long long)));
-        HIP_TRY(ctx, hipMemset(ctx->dTileQueue, 0, sizeof(unsigned long long)));
+        {   /* Higher dispatch priority than the main stream: when kernels of both streams wait for
+             * slots, the side stream's workgroups go first, which makes the two streams take turns
+             * from the first pair of launches on instead of starting — and draining — in step. */
+            int prLeast = 0, prGreatest = 0;
+            HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest));
+            HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->sideStream, hipStreamNonBlocking, prGreatest));
+        }
+        HIP_TRY(ctx, hipMalloc(&ctx->dTileQueue, 2 * sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMemset(ctx->dTileQueue, 0, 2 * sizeof(unsigned long long)));
         HIP_TRY(ctx, hipEventCreate(&ctx->evStart));
         HIP_TRY(ctx, hipEventCreate(&ctx->evStop));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming));
         return RT_OK;
     };
     if (int rc = init()) { /* the message stays readable through rt_last_error(NULL) */
@@ -174,6 +204,7 @@ int rt_create(int device_id, RtContext** out)
     if (getenv("RT_VERBOSE")) ctx->verbose = true;
     if (const char* f = getenv("RT_FUSE_FRAMES")) ctx->fuseFrames = atoi(f) != 0;
     if (const char* l = getenv("RT_LPT")) ctx->lptEnabled = atoi(l) != 0;
+    if (const char* t = getenv("RT_TWO_STREAMS")) ctx->twoStreams = atoi(t) != 0;
     *out = ctx;
     return RT_OK;
 }
@@ -195,6 +226,7 @@ void rt_destroy(RtContext* ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    if (ctx->sideStream) hipStreamSynchronize(ctx->sideStream);
     hipStreamSynchronize(ctx->stream);
     free_scene(ctx);
     hipFree(ctx->ownFrame);
@@ -205,6 +237,9 @@ void rt_destroy(RtContext* ctx)
     hipFree(ctx->dTileOrder);
     if (ctx->evStart) hipEventDestroy(ctx->evStart);
     if (ctx->evStop) hipEventDestroy(ctx->evStop);
+    if (ctx->evFork) hipEventDestroy(ctx->evFork);
+    if (ctx->evJoin) hipEventDestroy(ctx->evJoin);
+    if (ctx->sideStream) hipStreamDestroy(ctx->sideStream);
     if (ctx->ownStream) hipStreamDestroy(ctx->ownStream);
     delete ctx;
 }
@@ -212,7 +247,7 @@ void rt_destroy(RtContext* ctx)
 int rt_set_stream(RtContext* ctx, void* hip_stream)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
-    hipStreamSynchronize(ctx->stream);
+    hipStreamSynchronize(joined(ctx));
     flush_timer(ctx);
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->ownStream;
     return RT_OK;
@@ -235,7 +270,7 @@ int rt_resize(RtContext* ctx, int width, int height)
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     if (width <= 0 || height <= 0) return fail(ctx, RT_ERR_INVALID_ARG, "rt_resize: %dx%d", width, height);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
     ctx->W = width;
     ctx->H = height;
     ctx->localRows = local_rows_for(height, ctx->stripRows, ctx->partIndex, ctx->partCount);
@@ -251,8 +286,8 @@ int rt_resize(RtContext* ctx, int width, int height)
         }
     }
     if (bytes) {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->ownFrame, 0, bytes, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->ownAccum, 0, bytes, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->ownFrame, 0, bytes, joined(ctx)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->ownAccum, 0, bytes, joined(ctx)));
     }
     ctx->boundFrame = ctx->boundAccum = nullptr;
     ctx->orderTiles = 0; /* tile costs belong to the old geometry */
@@ -272,7 +307,7 @@ int rt_bind_render_targets(RtContext* ctx, void* d_frame, void* d_accum)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     if (((uintptr_t)d_frame | (uintptr_t)d_accum) & 15) return fail(ctx, RT_ERR_INVALID_ARG, "render targets must be 16-byte aligned");
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
     ctx->boundFrame = (float*)d_frame;
     ctx->boundAccum = (float*)d_accum;
     return RT_OK;
@@ -564,7 +599,7 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
         (n_nodes && !nodes) || (n_spheres && !spheres))
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_scene: bad pointer/count");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
 
     /* ---- validate + re-lay out the BVHs reachable from the models */
     SceneBuilder sb;
@@ -671,7 +706,7 @@ int rt_update_models(RtContext* ctx, const RtModel* models, int n_models)
         pack_material(models[i].material, mats[i]);
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
     HIP_TRY(ctx, hipMemcpy(ctx->dModels, dmodels.data(), sizeof(DModel) * n_models, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->dMaterials + ctx->nSpheres, mats.data(), sizeof(DMaterial) * n_models, hipMemcpyHostToDevice));
     {
@@ -694,7 +729,7 @@ int rt_update_spheres(RtContext* ctx, const RtSphere* spheres, int n_spheres)
     std::vector<DMaterial> mats(n_spheres);
     for (int i = 0; i < n_spheres; i++) pack_material(spheres[i].material, mats[i]);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
     HIP_TRY(ctx, hipMemcpy(ctx->dSpheres, sph.data(), sph.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->dMaterials, mats.data(), sizeof(DMaterial) * n_spheres, hipMemcpyHostToDevice));
     ctx->hSpheres.assign(spheres, spheres + n_spheres);
@@ -729,7 +764,7 @@ int rt_reset_accumulation(RtContext* ctx)
     if (n) {
         int blocks = (int)((n + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(rtk::rt_reset_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (float4*)accum, n);
+        hipLaunchKernelGGL(rtk::rt_reset_kernel, dim3(blocks), dim3(256), 0, joined(ctx), (float4*)accum, n);
         HIP_TRY(ctx, hipGetLastError());
     }
     ctx->frame = 1; /* RCM:71 */
@@ -789,14 +824,10 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
 {
     KArgs a;
     fill_args(ctx, frame0, nFrames, a);
-    int tiles = a.tilesX * a.tilesY;
+    const int tiles = a.tilesX * a.tilesY;
     if (tiles == 0) return RT_OK;
     const size_t stackBytes = (size_t)(ctx->stackEntries + RT_PIXEL_FIELDS) * RT_WAVE * sizeof(uint32_t);
     a.stackEntries = ctx->stackEntries;
-    /* Persistent launch: as many single-wave workgroups as the chip keeps resident
-     * (occupancy query x CUs), never more than there are tiles.  The first `grid` tiles are
-     * taken by blockIdx, the rest through the atomic queue, which counts monotonically
-     * across launches: this launch's queue indices start at tileQueueBase. */
     void (*kern)(const KArgs) = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_kernel<true, true> : rtk::rt_trace_kernel<false, true>)
                                                : (ctx->stats ? rtk::rt_trace_kernel<true, false> : rtk::rt_trace_kernel<false, false>);
     const int variant = (ctx->flatScene ? 2 : 0) + (ctx->stats ? 1 : 0);
@@ -806,16 +837,14 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         ctx->occPerCU[variant] = perCU > 0 ? perCU : 1;
         ctx->occBytes[variant] = stackBytes + 1;
     }
-    long long resident = (long long)ctx->occPerCU[variant] * ctx->numCUs;
-    int grid = (int)(resident < tiles ? resident : tiles);
-    if (ctx->gridOverride > 0) grid = ctx->gridOverride < tiles ? ctx->gridOverride : tiles;
+    const long long resident = (long long)ctx->occPerCU[variant] * ctx->numCUs;
     /* longest-chain-first queue order, learnt from the frames already rendered at this size */
     if (ctx->lptEnabled && ctx->orderTiles != tiles) {
         hipFree(ctx->dTileCost); ctx->dTileCost = nullptr;
         hipFree(ctx->dTileOrder); ctx->dTileOrder = nullptr;
         HIP_TRY(ctx, hipMalloc(&ctx->dTileCost, sizeof(uint32_t) * tiles));
         HIP_TRY(ctx, hipMalloc(&ctx->dTileOrder, sizeof(uint32_t) * tiles));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * tiles, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * tiles, joined(ctx)));
         ctx->orderTiles = tiles;
         ctx->orderValid = false;
         ctx->framesSinceResize = 0;
@@ -825,7 +854,7 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         const long long f = ctx->framesSinceResize;
         if (f >= ctx->nextSortAt) { /* re-sort once 1, 2, 4, 8, ... frames have been recorded */
             while (ctx->nextSortAt <= f) ctx->nextSortAt *= 2;
-            hipLaunchKernelGGL(rtk::rt_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->dTileCost, ctx->dTileOrder, tiles);
+            hipLaunchKernelGGL(rtk::rt_order_kernel, dim3(1), dim3(1024), 0, joined(ctx), ctx->dTileCost, ctx->dTileOrder, tiles);
             HIP_TRY(ctx, hipGetLastError());
             ctx->orderValid = true;
         }
@@ -833,12 +862,44 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         a.tileOrder = ctx->orderValid ? ctx->dTileOrder : nullptr;
         ctx->framesSinceResize += nFrames;
     }
-    if (ctx->verbose) fprintf(stderr, "[raytrace_hip] launch variant=%d tiles=%d grid=%d perCU=%d lds=%zu\n", variant, tiles, grid, ctx->occPerCU[variant], stackBytes);
-    a.tileQueue = ctx->dTileQueue;
-    a.tileQueueBase = ctx->tileQueueNext - (unsigned long long)grid;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(RT_WAVE), stackBytes, ctx->stream, a);
-    HIP_TRY(ctx, hipGetLastError()); /* a refused launch ran no wave: the device counter did not move */
-    ctx->tileQueueNext += (unsigned long long)(tiles - grid) + (unsigned long long)grid; /* each wave overshoots once */
+    /* Persistent launches.  Queue position q of part p is entry q*parts + p of the (longest chain
+     * first) tile order, so the parts are disjoint and equally heavy.  Each kernel is given as
+     * many single-wave workgroups as the chip keeps resident (occupancy query x CUs), never more
+     * than it has tiles: its first `grid` positions are taken by blockIdx, the rest through the
+     * part's atomic queue, which counts monotonically across launches (this launch's positions
+     * start at tileQueueBase).
+     * Two parts on two streams while the context runs on its own stream: a kernel ends with a
+     * drain phase as long as one pixel's serial chain, during which waves retire one by one;
+     * the other stream's kernel — different pixels, no dependence — picks up every slot that
+     * frees, and the two streams settle into taking turns.  With a caller-provided stream the
+     * caller's stream order is the contract, so there is one kernel on that stream. */
+    const int parts = (ctx->twoStreams && ctx->stream == ctx->ownStream && ctx->sideStream && tiles >= 2) ? 2 : 1;
+    if (parts == 2 && ctx->needFork) { /* the side stream follows what the main stream holds so far */
+        HIP_TRY(ctx, hipEventRecord(ctx->evFork, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->sideStream, ctx->evFork, 0));
+        ctx->needFork = false;
+    }
+    for (int p = 0; p < parts; p++) {
+        const int partTiles = (tiles - p + parts - 1) / parts;
+        int grid = (int)(resident < partTiles ? resident : partTiles);
+        if (ctx->gridOverride > 0) grid = ctx->gridOverride < partTiles ? ctx->gridOverride : partTiles;
+        a.launchTiles = partTiles;
+        a.orderOffset = p;
+        a.orderStride = parts;
+        a.tileQueue = ctx->dTileQueue + p;
+        /* One kernel alone: all its workgroups become resident at once, the first `grid` positions go
+         * by blockIdx and only the rest through the queue.  Two kernels sharing the chip: workgroups
+         * are dispatched as slots free up, possibly late, so every position — the longest chains
+         * first — comes from the queue. */
+        a.queueStart = parts == 2 ? 1 : 0;
+        a.tileQueueBase = ctx->tileQueueNext[p] - (a.queueStart ? 0ull : (unsigned long long)grid);
+        if (ctx->verbose) fprintf(stderr, "[raytrace_hip] launch variant=%d part=%d/%d tiles=%d grid=%d perCU=%d lds=%zu\n", variant, p, parts, partTiles, grid, ctx->occPerCU[variant], stackBytes);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(RT_WAVE), stackBytes, p == 0 ? ctx->stream : ctx->sideStream, a);
+        HIP_TRY(ctx, hipGetLastError()); /* a refused launch ran no wave: the device counter did not move */
+        /* every tile not taken by blockIdx is one successful fetch, and each of the grid waves overshoots once */
+        ctx->tileQueueNext[p] += (unsigned long long)partTiles + (a.queueStart ? (unsigned long long)grid : 0ull);
+        if (p == 1) ctx->sideDirty = true;
+    }
     ctx->pixelFrames += (uint64_t)ctx->localRows * ctx->W * nFrames;
     return RT_OK;
 }
@@ -895,7 +956,7 @@ int rt_render_frames(RtContext* ctx, int n)
 int rt_synchronize(RtContext* ctx)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
     flush_timer(ctx);
     return RT_OK;
 }
@@ -908,7 +969,7 @@ int rt_timer_begin(RtContext* ctx)
     flush_timer(ctx);
     if (ctx->timerState == 1) return fail(ctx, RT_ERR_STATE, "rt_timer_begin: timer already running");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipEventRecord(ctx->evStart, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->evStart, joined(ctx)));
     ctx->timerState = 1;
     return RT_OK;
 }
@@ -917,7 +978,7 @@ int rt_timer_end(RtContext* ctx)
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     if (ctx->timerState != 1) return fail(ctx, RT_ERR_STATE, "rt_timer_end without rt_timer_begin");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipEventRecord(ctx->evStop, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->evStop, joined(ctx)));
     ctx->timerState = 2;
     return RT_OK;
 }
@@ -928,7 +989,7 @@ static int read_target(RtContext* ctx, const float* src, float* rgba, size_t byt
     size_t want = (size_t)ctx->localRows * ctx->W * 16;
     if (!rgba || bytes != want) return fail(ctx, RT_ERR_INVALID_ARG, "read: need exactly %zu bytes, got %zu", want, bytes);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
     flush_timer(ctx);
     if (bytes) HIP_TRY(ctx, hipMemcpy(rgba, src, bytes, hipMemcpyDeviceToHost));
     return RT_OK;
@@ -965,9 +1026,9 @@ int rt_display(RtContext* ctx, int frame, int use_accumulated, float* rgba, size
     HIP_TRY(ctx, hipMalloc(&tmp, bytes));
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(rtk::rt_display_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const float4*)src, tmp, n, frame);
+    hipLaunchKernelGGL(rtk::rt_display_kernel, dim3(blocks), dim3(256), 0, joined(ctx), (const float4*)src, tmp, n, frame);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(joined(ctx));
     if (e == hipSuccess) e = hipMemcpy(rgba, tmp, bytes, hipMemcpyDeviceToHost);
     hipFree(tmp);
     if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_display: %s", hipGetErrorString(e));
@@ -987,9 +1048,9 @@ int rt_display_srgb8(RtContext* ctx, int frame, int use_accumulated, int flip_y,
     HIP_TRY(ctx, hipMalloc(&tmp, bytes));
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(rtk::rt_display_srgb8_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const float4*)src, tmp, ctx->W, ctx->localRows, frame, flip_y);
+    hipLaunchKernelGGL(rtk::rt_display_srgb8_kernel, dim3(blocks), dim3(256), 0, joined(ctx), (const float4*)src, tmp, ctx->W, ctx->localRows, frame, flip_y);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(joined(ctx));
     if (e == hipSuccess) e = hipMemcpy(rgba8, tmp, bytes, hipMemcpyDeviceToHost);
     hipFree(tmp);
     if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_display_srgb8: %s", hipGetErrorString(e));
@@ -1002,7 +1063,7 @@ int rt_write_accumulated(RtContext* ctx, const float* rgba, size_t bytes)
     const size_t want = (size_t)ctx->localRows * ctx->W * 16;
     if (!rgba || bytes != want) return fail(ctx, RT_ERR_INVALID_ARG, "rt_write_accumulated: need exactly %zu bytes, got %zu", want, bytes);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
     if (bytes) HIP_TRY(ctx, hipMemcpy(ctx->boundAccum ? ctx->boundAccum : ctx->ownAccum, rgba, bytes, hipMemcpyHostToDevice));
     return RT_OK;
 }
@@ -1018,7 +1079,7 @@ int rt_reset_counters(RtContext* ctx)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
     flush_timer(ctx);
     HIP_TRY(ctx, hipMemset(ctx->dCounters, 0, sizeof(unsigned long long) * RT_COUNTER_SLOTS * RT_COUNTER_FIELDS));
     ctx->pixelFrames = 0;
@@ -1031,7 +1092,7 @@ int rt_get_counters(RtContext* ctx, RtCounters* out)
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     if (!out) return fail(ctx, RT_ERR_INVALID_ARG, "rt_get_counters: null out");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
     flush_timer(ctx);
     std::vector<unsigned long long> h((size_t)RT_COUNTER_SLOTS * RT_COUNTER_FIELDS);
     HIP_TRY(ctx, hipMemcpy(h.data(), ctx->dCounters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1058,7 +1119,7 @@ int rt_debug_phase_profile(RtContext* ctx, uint64_t* out, int n)
 {
     if (!ctx || !out || n < 2 * RT_N_PHASES) return fail(ctx, RT_ERR_INVALID_ARG, "rt_debug_phase_profile: need %d entries", 2 * RT_N_PHASES);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
     std::vector<unsigned long long> h((size_t)RT_COUNTER_SLOTS * RT_COUNTER_FIELDS);
     HIP_TRY(ctx, hipMemcpy(h.data(), ctx->dCounters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int f = 0; f < 2 * RT_N_PHASES; f++) {
@@ -1095,9 +1156,9 @@ int rt_debug_intersect(RtContext* ctx, const float* origins, const float* dirs, 
     HIP_TRY(ctx, hipMemcpy(dD.p, dirs, (size_t)n * 12, hipMemcpyHostToDevice));
     KArgs a;
     fill_args(ctx, 1, 1, a);
-    hipLaunchKernelGGL(rtk::rt_debug_intersect_kernel, dim3((n + RT_WAVE - 1) / RT_WAVE), dim3(RT_WAVE), 0, ctx->stream, a, dO.f(), dD.f(), n, dR.f());
+    hipLaunchKernelGGL(rtk::rt_debug_intersect_kernel, dim3((n + RT_WAVE - 1) / RT_WAVE), dim3(RT_WAVE), 0, joined(ctx), a, dO.f(), dD.f(), n, dR.f());
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
     HIP_TRY(ctx, hipMemcpy(out10, dR.p, (size_t)n * 40, hipMemcpyDeviceToHost));
     return RT_OK;
 }
@@ -1114,9 +1175,9 @@ int rt_debug_math_eval(RtContext* ctx, int op, const float* x, const float* y, f
     HIP_TRY(ctx, dR.alloc((size_t)n * 4));
     HIP_TRY(ctx, hipMemcpy(dX.p, x, (size_t)n * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dY.p, y, (size_t)n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(rtk::rt_debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, op, dX.f(), dY.f(), dR.f(), n);
+    hipLaunchKernelGGL(rtk::rt_debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, joined(ctx), op, dX.f(), dY.f(), dR.f(), n);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
     HIP_TRY(ctx, hipMemcpy(out, dR.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return RT_OK;
 }

@@ -116,7 +116,11 @@ struct KArgs {
     float rcpSpp;                /* 1 / NumRaysPerPixel   — RC:581 */
     /* counters: RT_COUNTER_SLOTS x RT_COUNTER_FIELDS u64 */
     unsigned long long* counters;
-    /* persistent waves: global tile queue (monotonic; this launch's tiles start at tileQueueBase) */
+    /* persistent waves: this launch renders launchTiles tiles; its queue position q is entry
+     * q*orderStride + orderOffset of the tile order.  Positions beyond the grid come from a global
+     * atomic counter (monotonic across launches; this launch's positions start at tileQueueBase) */
+    int32_t launchTiles, orderOffset, orderStride;
+    int32_t queueStart;          /* 1: the first position of every wave comes from the queue too (not blockIdx) */
     unsigned long long* tileQueue;
     unsigned long long tileQueueBase;
     /* longest-chain-first scheduling: queue position -> tile (null = identity), and the

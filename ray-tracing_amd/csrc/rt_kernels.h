@@ -634,9 +634,9 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
     } while (0)
     {
         const RT_CAS KArgs& c = cold_args();
-        const int nTiles = c.tilesX * c.tilesY;
         int tile = (int)blockIdx.x;
-        if (tile < nTiles && c.nFrames > 0) {
+        if (tile < c.launchTiles && c.nFrames > 0 && !c.queueStart) {
+            tile = tile * c.orderStride + c.orderOffset;
             if (c.tileOrder) tile = (int)c.tileOrder[tile];
             RT_SET_POOL(c, tile);
         } else {
@@ -678,7 +678,8 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
                 int next = 0;
                 if (lane == 0) next = (int)(atomicAdd(c.tileQueue, 1ull) - c.tileQueueBase);
                 next = __builtin_amdgcn_readfirstlane(next);
-                if (next >= c.tilesX * c.tilesY) { queueEmpty = true; break; }
+                if (next >= c.launchTiles) { queueEmpty = true; break; }
+                next = next * c.orderStride + c.orderOffset;
                 if (c.tileOrder) next = (int)c.tileOrder[next];
                 RT_SET_POOL(c, next);
             }
