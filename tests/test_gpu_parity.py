@@ -290,6 +290,50 @@ def test_persistent_grid_size_does_not_change_results(pkg, api, orc, grid, monke
     assert [ca[k] for k in KEYS] == [cb[k] for k in KEYS]
 
 
+@pytest.mark.parametrize("two", ["0", "1"])
+def test_one_or_two_render_streams_same_bits(pkg, api, orc, two, monkeypatch):
+    """Default: every frame is two kernels over disjoint tile halves on two streams (joined lazily at
+    the next non-render call); RT_TWO_STREAMS=0: one kernel on the main stream.  Interleaved with
+    resets, reads and parameter updates so that the fork/join bookkeeping is exercised."""
+    monkeypatch.setenv("RT_TWO_STREAMS", two)
+    out = []
+    for lib in (api, orc):
+        tr = lib.create_tracer(0 if lib is api else 8)
+        sc = pkg.scenes.get(3)
+        mgr = sc.make_manager(tr, lib, 88, 56)
+        mgr.OnEnable(renderSeed=5)
+        for _ in range(3):
+            mgr.RenderFrame()
+        first = tr.read_accumulated().copy()
+        mgr.models[7].transform = pkg.Transform((-0.5, 0.8, 0.2), (10, 40, 0), (0.8, 0.8, 0.8))
+        mgr.ResetAccumulatedRender()
+        mgr.RenderFrame()
+        mgr.RenderFrames(5)
+        mgr.RenderFrame()
+        out.append((first, tr.read_accumulated().copy(), tr.read_frame().copy(), tr.counters()["segments"]))
+        tr.close()
+    (a1, a2, a3, sa), (b1, b2, b3, sb) = out
+    assert bits_equal(a1, b1) and bits_equal(a2, b2) and bits_equal(a3, b3) and sa == sb
+
+
+def test_caller_stream_keeps_stream_order(pkg, api, orc):
+    """rt_set_stream: launches go to the caller's stream only (no second stream), results unchanged."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    stream = ctypes.c_void_p()
+    g = api.create_tracer(0)   # (rt_create selects the device)
+    assert hip.hipStreamCreate(ctypes.byref(stream)) == 0 and stream.value
+    g.set_stream(stream.value)
+    c = orc.create_tracer(8)
+    a, _ = render(pkg, api, g, 3, 72, 40, 3, 2)
+    assert hip.hipStreamSynchronize(stream) == 0
+    b, _ = render(pkg, orc, c, 3, 72, 40, 3, 2)
+    g.set_stream(None)
+    g.close(), c.close()
+    assert hip.hipStreamDestroy(stream) == 0
+    assert bits_equal(a, b)
+
+
 def test_tile_order_learning_does_not_change_results(pkg, api, orc):
     """9 frames: the longest-chain-first queue order is re-learnt after frames 1, 2, 4 and 8."""
     a, b, ca, cb = pair(pkg, api, orc, 2, 96, 54, 9)
