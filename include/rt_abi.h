@@ -157,8 +157,12 @@ int rt_create(int device_id, RtContext** out);
 void rt_destroy(RtContext* ctx);
 const char* rt_last_error(const RtContext* ctx); /* ctx may be NULL: global msg */
 
-/* Run launches on an existing hipStream_t (e.g. torch's current stream); NULL =
- * the context's own stream. */
+/* Run launches on an existing hipStream_t (e.g. torch's current stream): every kernel of
+ * this context is then enqueued on that stream, in call order.  NULL = the context's own
+ * stream (the default); in that mode a frame may be launched as several kernels on internal
+ * streams (RT_TWO_STREAMS=0 in the environment forbids it), and only the synchronising
+ * calls — rt_synchronize, the rt_read_x / rt_display_x family, rt_get_counters — order host code
+ * after them. */
 int rt_set_stream(RtContext* ctx, void* hip_stream);
 
 /* ---- render targets: RCM:126-141 InitTexturesAndBuffers -------------------- */

@@ -750,7 +750,9 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
                         laneDone = true;
                         if (c.tileCost) { /* longest serial chain of this tile's pixels: next frame's queue order */
                             const uint32_t prow = pixLinear / c.W, pcol = pixLinear - prow * c.W;
-                            atomicMax(c.tileCost + (prow >> 3) * (uint32_t)c.tilesX + (pcol >> 3), (segments - PXU(PX_SEGSTART)) / (uint32_t)c.nFrames);
+                            uint32_t* const slot = c.tileCost + (prow >> 3) * (uint32_t)c.tilesX + (pcol >> 3);
+                            const uint32_t chain = (segments - PXU(PX_SEGSTART)) / (uint32_t)c.nFrames;
+                            if (chain > *slot) atomicMax(slot, chain); /* the plain read may be stale (lower): then the atomic decides */
                         }
                     } else {
                         rng = PXU(PX_INDEX) + (uint32_t)frame * 719393u + (uint32_t)c.seed;
