@@ -44,6 +44,10 @@
 #ifndef RT_MIN_WAVES_PER_SIMD
 #define RT_MIN_WAVES_PER_SIMD 5
 #endif
+/* inner steps per vote won by phase B (lanes that reach a leaf or run out wait for the next vote) */
+#ifndef RT_INNER_BURST
+#define RT_INNER_BURST 3
+#endif
 
 namespace rtk {
 
@@ -207,7 +211,7 @@ __device__ __forceinline__ void tri_test(const DTri* __restrict__ tris, int triI
     float u = rt_dot(edgeAC, rayOffsetPerp) * invDet;
     float v = -rt_dot(edgeAB, rayOffsetPerp) * invDet;
     float w = 1 - u - v;
-    bool keep = cull ? determinant >= 1E-8f : rt_abs(determinant) >= 1E-8f;
+    bool keep = (cull ? determinant : rt_abs(determinant)) >= 1E-8f; /* cull ? det >= eps : |det| >= eps */
     bool didHit = keep && dst > 0 && u >= 0 && v >= 0 && w >= 0;
     if (didHit && dst < bestDst) {
         bestDst = dst;
@@ -450,7 +454,12 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
                 if (!(t.cur & RT_CODE_LEAF)) t.linv = rt_v3(rt_rcp(t.ldir.x), rt_rcp(t.ldir.y), rt_rcp(t.ldir.z));
             }
         } else if (nB >= nC) {
-            if (atInner) { /* ---- B: one inner node, RC:262-282 */
+            /* a short burst of inner steps per vote won (lanes that reach a leaf or run out of nodes
+             * wait for the next vote): 3 measured best — 1 pays a vote per step, "until no lane
+             * is at an inner node" (the classic while-while) idles most lanes most of the time */
+#pragma clang loop unroll(disable)
+            for (int burst = 0; burst < RT_INNER_BURST; burst++)
+            if (t.cur < RT_CODE_DONE) { /* ---- B: one inner node, RC:262-282 */
                 if (STATS && !t.rootStep) st.inner++;
                 t.rootStep = false;
                 phase_mark<STATS>(st, PH_INNER);
