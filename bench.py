@@ -38,12 +38,12 @@ import __graft_entry__ as graft  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(pkg, scene_id, width, height, min_s=10.0, max_frames=4):
-    """The CPU oracle (a port of the reference's loop, ONE thread) timed on a bounded
-    sample of the same workload: whole frames 1, 2, ... of the same scene at the same
-    resolution until at least `min_s` seconds of CPU work are done."""
+def cpu_baseline(pkg, scene_id, width, height, min_s=10.0, max_frames=4, threads=1):
+    """The CPU oracle (a port of the reference's loop; ONE thread unless told otherwise) timed on
+    a bounded sample of the same workload: whole frames 1, 2, ... of the same scene at the same
+    resolution until at least `min_s` seconds of wall time are spent."""
     orc = graft.load_oracle()
-    tr = orc.create_tracer(threads=1)
+    tr = orc.create_tracer(threads=threads)
     sc = pkg.scenes.get(scene_id)
     mgr = sc.make_manager(tr, orc, width, height)
     mgr.OnEnable(renderSeed=1)
@@ -57,8 +57,8 @@ def cpu_baseline(pkg, scene_id, width, height, min_s=10.0, max_frames=4):
     c = tr.counters()
     tr.close()
     return {
-        "value": c["segments"] / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-        "sample": f"oracle/rt_oracle.cpp (g++ -O2, strict fp32), 1 thread: frames 1..{frames} of the same scene at "
+        "value": c["segments"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": f"oracle/rt_oracle.cpp (g++ -O2, strict fp32), {threads} thread(s): frames 1..{frames} of the same scene at "
                   f"{width}x{height} ({c['segments']} segments in {dt:.1f} s)",
         "nproc": os.cpu_count(),
     }
@@ -277,6 +277,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, args.config, W, H)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            # informational: the same port on the host's cores (row bands of the image per thread)
+            nthr = min(os.cpu_count() or 1, 64)
+            if nthr > 1:
+                out["cpu_baseline_threads"] = cpu_baseline(pkg, args.config, W, H, min_s=4.0, max_frames=64, threads=nthr)
         print(json.dumps(out), flush=True)
 
     tracer.close()
