@@ -64,15 +64,13 @@ struct DModel {
     int32_t cullBackface; /* material.flag != GLASS (RC:355) */
     int32_t pad[5];
 };
-/* Conservative world-space stand-in for a model's root step (see begin_intersect): the
- * root's two child boxes, transformed to world space and inflated; `always` = no filtering
- * (leaf root, or a matrix that cannot be inverted robustly). 64 B, scalar-loaded. */
+/* Conservative world-space stand-in for a model's root step (see begin_intersect): the union of
+ * the root's two child boxes, transformed to world space and inflated; `always` = no filtering
+ * (leaf root, or a matrix that cannot be inverted robustly). 32 B, scalar-loaded. */
 struct DFilter {
-    float aMin[3], aMax[3];
     float bMin[3], bMax[3];
     uint32_t always;
     uint32_t innerRoot;
-    uint32_t pad[2];
 };
 struct DMaterial {
     float diffuseCol[4], emissionCol[4], specularCol[4], absorption[4];

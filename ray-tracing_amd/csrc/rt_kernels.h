@@ -324,9 +324,9 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
      * In the reference every model costs a ray two matrix-vector products, three divides
      * and the root's two box tests (RC:351-353, 269-270) before most rays find they miss it.
      * A model whose root children are both missed contributes nothing (nothing is pushed,
-     * RC:280-281).  Here that decision is taken CONSERVATIVELY in world space: the root's two
-     * child boxes were transformed to world space and inflated on upload (rt_context.hip,
-     * make_filter), so one slab test per box with the world ray — no transform, one
+     * RC:280-281).  Here that decision is taken CONSERVATIVELY in world space: the union of the
+     * root's two child boxes was transformed to world space and inflated on upload
+     * (rt_context.hip, make_filters), so one slab test with the world ray — no transform, one
      * reciprocal per segment — never rejects a model the reference would descend into; the
      * models that pass get the reference's exact arithmetic in the per-lane traversal, in
      * model order.  The filter only saves work: results and counters do not depend on it
@@ -341,12 +341,10 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
             const RT_CAS DFilter& F = cf[m];
             bool keep = true;
             if (!F.always) {
-                float aMin[3] = {F.aMin[0], F.aMin[1], F.aMin[2]}, aMax[3] = {F.aMax[0], F.aMax[1], F.aMax[2]};
                 float bMin[3] = {F.bMin[0], F.bMin[1], F.bMin[2]}, bMax[3] = {F.bMax[0], F.bMax[1], F.bMax[2]};
-                float dA = box_dst(rpos, winv, aMin, aMax);
-                float dB = box_dst(rpos, winv, bMin, bMax);
+                const float dB = box_dst(rpos, winv, bMin, bMax);
                 /* box_dst returns +inf for a miss; '<=' (not '<') on the distance keeps it conservative */
-                keep = farOrigin || (dA < RT_INF && dA <= h.dst) || (dB < RT_INF && dB <= h.dst);
+                keep = farOrigin || (dB < RT_INF && dB <= h.dst);
             }
             if (STATS) {
                 st.inner += F.innerRoot;
