@@ -106,6 +106,27 @@ class Transform:
         return self.rotation_matrix()[:, 2]
 
 
+class MatrixTransform:
+    """A Transform given directly by its localToWorldMatrix (4x4, row/col) — e.g. the product of a
+    parent chain read from a Unity scene file (unityscene.py)."""
+
+    def __init__(self, matrix):
+        self.matrix = np.asarray(matrix, dtype=np.float64).reshape(4, 4)
+
+    @property
+    def localToWorldMatrix(self):
+        return self.matrix
+
+    @property
+    def worldToLocalMatrix(self):
+        return np.linalg.inv(self.matrix)
+
+    @property
+    def forward(self):
+        f = self.matrix[:3, 2]
+        return f / (np.linalg.norm(f) or 1.0)
+
+
 def matrix_to_abi(m):
     """4x4 (row, col) -> Unity Matrix4x4 memory order (column-major 16 floats)."""
     return (np.asarray(m, dtype=np.float64).T.reshape(16) + 0.0).astype(np.float32)  # + 0.0: no negative zeros

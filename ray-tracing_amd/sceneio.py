@@ -22,7 +22,7 @@ import os
 import numpy as np
 
 from . import meshes
-from .manager import Camera, Model, RayTracingMaterial, Sphere, Transform
+from .manager import Camera, MatrixTransform, Model, RayTracingMaterial, Sphere, Transform
 from .scenes import SceneDescription
 
 MATERIAL_FIELDS = ["flag", "diffuseCol", "emissionCol", "specularCol", "absorption", "absorptionMultiplier",
@@ -109,7 +109,14 @@ def _material(d):
 
 def _transform(d):
     d = d or {}
+    if "matrix" in d:  # localToWorldMatrix given directly (e.g. a Unity parent chain, unityscene.py)
+        return MatrixTransform(d["matrix"])
     return Transform(d.get("position", (0, 0, 0)), d.get("euler", (0, 0, 0)), d.get("scale", (1, 1, 1)))
+
+
+class _ForwardOnly:
+    def __init__(self, forward):
+        self.forward = np.asarray(forward, dtype=np.float64)
 
 
 def scene_from_dict(d, base_dir="."):
@@ -124,10 +131,18 @@ def scene_from_dict(d, base_dir="."):
     for k in settings:
         if k not in SETTING_FIELDS:
             raise ValueError(f"unknown manager setting {k!r}")
+    if "sunForward" in d:  # RCM:176 reads sunTransform.forward only
+        settings["sunTransform"] = _ForwardOnly(d["sunForward"])
     return SceneDescription(d.get("name", "scene"), w, h, int(d.get("frames", 1)), settings, camera, models, spheres)
 
 
-def load_scene(path):
+def load_scene(path, **unity_kw):
+    """A JSON scene, or a Unity `.unity` scene file (converted by unityscene.py; unity_kw =
+    assets_dir / stand_ins / width / height / frames)."""
+    if path.lower().endswith(".unity"):
+        from . import unityscene
+        d, _notes = unityscene.load_unity_scene(path, **unity_kw)
+        return scene_from_dict(d, os.path.dirname(os.path.abspath(path)))
     with open(path) as f:
         return scene_from_dict(json.load(f), os.path.dirname(os.path.abspath(path)))
 
@@ -151,12 +166,15 @@ def scene_to_dict(scene, mesh_specs=None):
         return {k: (list(getattr(x, k)) if isinstance(getattr(x, k), tuple) else getattr(x, k)) for k in MATERIAL_FIELDS}
 
     def tf(t):
+        if isinstance(t, MatrixTransform):
+            return {"matrix": t.matrix.tolist()}
         return {"position": list(t.position), "euler": list(t.euler), "scale": list(t.scale)}
     cam = tf(scene.camera.transform)
     cam["fieldOfView"] = scene.camera.fieldOfView
     return {
         "name": scene.name, "width": scene.width, "height": scene.height, "frames": scene.frames,
-        "settings": {k: (list(v) if isinstance(v, tuple) else v) for k, v in scene.settings.items()},
+        "settings": {k: (list(v) if isinstance(v, tuple) else v) for k, v in scene.settings.items() if k != "sunTransform"},
+        **({"sunForward": [float(x) for x in scene.settings["sunTransform"].forward]} if scene.settings.get("sunTransform") is not None else {}),
         "camera": cam, "meshes": out_meshes,
         "models": [{"mesh": names[id(m.Mesh)], "name": m.name, "transform": tf(m.transform), "material": mat(m.material)}
                    for m in scene.models],

@@ -4,6 +4,11 @@
     python tools/rt_render.py 3 --frames 8 --png out.png
     python tools/rt_render.py scene.json --size 960x540 --frames 32 --png out.png --pfm out.pfm --checkpoint ck.npz
     python tools/rt_render.py scene.json --resume ck.npz --frames 32 --png more.png
+    python tools/rt_render.py "Assets/Scenes/Glass Balls.unity" --stand-in Icosphere.obj=icosphere:4 --dump-json balls.json
+
+A Unity scene file is converted by ray_tracing_amd/unityscene.py; meshes that only exist inside the
+engine or are missing on disk need `--stand-in NAME=SPEC` (SPEC: cube | quad | rounded_cube |
+icosphere:SUBDIV[:DISPLACEMENT_SEED] | a JSON mesh spec).
 """
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,9 +23,28 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--png"); ap.add_argument("--pfm"); ap.add_argument("--checkpoint"); ap.add_argument("--resume")
     ap.add_argument("--dump-json", help="write the scene as JSON and exit (no GPU needed)")
+    ap.add_argument("--assets", help="Unity Assets directory (for .unity scenes; default: the scene's project)")
+    ap.add_argument("--stand-in", action="append", default=[], metavar="NAME=SPEC", help="mesh stand-in for a .unity scene")
     a = ap.parse_args()
     pkg = g.load_package()
-    scene = pkg.scenes.get(int(a.scene)) if a.scene.isdigit() else pkg.sceneio.load_scene(a.scene)
+
+    def mesh_spec(text):
+        if text.startswith("{"):
+            return json.loads(text)
+        parts = text.split(":")
+        spec = {"type": parts[0]}
+        if parts[0] == "icosphere":
+            spec["subdivisions"] = int(parts[1]) if len(parts) > 1 else 3
+            if len(parts) > 2:
+                spec["displacement_seed"] = int(parts[2])
+        return spec
+    if a.scene.isdigit():
+        scene = pkg.scenes.get(int(a.scene))
+    elif a.scene.lower().endswith(".unity"):
+        stand = dict((kv.split("=", 1)[0], mesh_spec(kv.split("=", 1)[1])) for kv in a.stand_in)
+        scene = pkg.sceneio.load_scene(a.scene, assets_dir=a.assets, stand_ins=stand)
+    else:
+        scene = pkg.sceneio.load_scene(a.scene)
     if a.dump_json:
         pkg.sceneio.save_scene(a.dump_json, scene)
         return
