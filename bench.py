@@ -250,7 +250,8 @@ def main():
             "config": {
                 "workload": f"{scene.name}: {W}x{H}, {scene.settings['numRaysPerPixel']} spp/frame, "
                             f"{scene.settings['maxBounceCount']} bounces, {n_spheres} spheres + {n_models} models "
-                            f"({scene.unique_triangles()} triangles); BASELINE.json configs[{args.config - 1}]",
+                            f"({scene.unique_triangles()} triangles); "
+                            + (f"BASELINE.json configs[{args.config - 1}]" if args.config <= 5 else "the reference's own scene file, not a BASELINE config"),
                 "parallelism": "single GPU" if world == 1 else f"{W}x{H} image row-tiled, cyclic 8-row strips over {world} GPUs "
                                f"({args.scaling} scaling), RCCL gather at readback",
                 "renderSeed": 1, "first_timed_frame": first_frame,

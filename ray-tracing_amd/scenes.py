@@ -192,7 +192,22 @@ def config5(subdivisions=6, n_meshes=12):
     return SceneDescription("config5_1Mtris_multimesh", 3840, 2160, 32, settings, cam, models=models)
 
 
-CONFIGS = {1: config1, 2: config2, 3: config3, 4: config4, 5: config5}
+def glass_balls(numRaysPerPixel=8, width=1920, height=1080):
+    """One of the reference's own scenes, `Assets/Scenes/Glass Balls.unity`: Cornell room with
+    checkered walls, five ceiling lights and six glass balls — 17 models, every parameter as
+    serialized in the scene file (scenes_data/glass_balls.json, written by unityscene.py), except
+    that `Icosphere.obj` (a missing blob upstream) is a subdivision-4 icosphere and that the
+    manager's 1 ray per pixel per frame is raised to the BASELINE's 8 spp per frame."""
+    import os
+    from . import sceneio
+    sc = sceneio.load_scene(os.path.join(os.path.dirname(os.path.abspath(__file__)), "scenes_data", "glass_balls.json"))
+    sc.name = "glass_balls_reference_scene"
+    sc.width, sc.height = width, height
+    sc.settings["numRaysPerPixel"] = numRaysPerPixel
+    return sc
+
+
+CONFIGS = {1: config1, 2: config2, 3: config3, 4: config4, 5: config5, 6: glass_balls}
 
 
 def get(config_id, **kw):

@@ -30,6 +30,8 @@ CASES = {
     # BVH quality Low and Disabled produce different trees, same image path
     "config3_48x27_lowq": (3, 48, 27, 1, {}, {"bvhQuality": 0}),
     "config3_48x27_nobvh": (3, 48, 27, 1, {}, {"bvhQuality": 2}),
+    # the reference's own Glass Balls scene (scenes_data/glass_balls.json): 17 models, checkered walls, glass
+    "glassballs_72x40_f2": (6, 72, 40, 2, {}, {}),
 }
 KEYS = ["segments", "innerSteps", "leafSteps", "triTests", "sphereTests", "modelVisits", "pixelFrames"]
 

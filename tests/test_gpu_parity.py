@@ -45,6 +45,7 @@ def pair(pkg, api, orc, cfg, w, h, frames, seed=1, scene_kw=None, tweak=None, st
     (3, 61, 35, 2, None),            # ragged tiles
     (4, 128, 72, 1, {"subdivisions": 4}),   # depth of field + glass blob
     (5, 96, 54, 1, {"subdivisions": 3, "n_meshes": 12}),  # many models, 12 bounces
+    (6, 139, 78, 2, None),           # the reference's Glass Balls scene (17 models, matrix transforms)
 ])
 def test_bit_exact_against_oracle(pkg, api, orc, cfg, w, h, frames, kw):
     a, b, ca, cb = pair(pkg, api, orc, cfg, w, h, frames, scene_kw=kw)
