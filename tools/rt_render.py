@@ -8,7 +8,8 @@
 
 A Unity scene file is converted by ray_tracing_amd/unityscene.py; meshes that only exist inside the
 engine or are missing on disk need `--stand-in NAME=SPEC` (SPEC: cube | quad | rounded_cube |
-icosphere:SUBDIV[:DISPLACEMENT_SEED] | a JSON mesh spec).
+icosphere:SUBDIV[:DISPLACEMENT_SEED[:RADIUS]] | a JSON mesh spec); a stand-in has to have the
+asset's native size, the scene only stores the Transform on top of it.
 """
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -35,8 +36,10 @@ def main():
         spec = {"type": parts[0]}
         if parts[0] == "icosphere":
             spec["subdivisions"] = int(parts[1]) if len(parts) > 1 else 3
-            if len(parts) > 2:
+            if len(parts) > 2 and parts[2]:
                 spec["displacement_seed"] = int(parts[2])
+            if len(parts) > 3:
+                spec["radius"] = float(parts[3])   # the stand-in must have the asset's native size
         return spec
     if a.scene.isdigit():
         scene = pkg.scenes.get(int(a.scene))
