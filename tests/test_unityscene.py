@@ -94,3 +94,31 @@ def test_scene_renders_through_the_manager(pkg, orc, converted, tmp_path):
     again = pkg.sceneio.scene_from_dict(pkg.sceneio.scene_to_dict(sc))
     assert np.allclose(again.models[1].transform.localToWorldMatrix, sc.models[1].transform.localToWorldMatrix)
     tr.close()
+
+
+REF_SCENES = "/root/reference/Assets/Scenes"
+STAND_INS = {"Icosphere.obj": {"type": "icosphere", "subdivisions": 4},
+             "Dragon_80K.obj": {"type": "icosphere", "subdivisions": 5, "displacement_seed": 4, "radius": 0.2},
+             "Water.fbx": {"type": "quad"}, "Text.fbx": {"type": "cube"}}
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SCENES), reason="reference checkout not present (it is only on the build machine)")
+def test_reference_scenes_convert_and_glass_balls_matches_the_committed_transcription(pkg):
+    """Provenance of ray-tracing_amd/scenes_data/glass_balls.json: converting the reference's scene
+    file again gives the same models, matrices, materials, settings and camera."""
+    counts = {}
+    for name in ("Glass Balls", "Glass Dragon", "Sphere Refract", "Splash", "Text"):
+        d, _ = pkg.unityscene.load_unity_scene(os.path.join(REF_SCENES, name + ".unity"), stand_ins=STAND_INS)
+        counts[name] = len(d["models"])
+        assert d["camera"]["fieldOfView"] > 0 and d["settings"]["maxBounceCount"] > 0
+        for m in d["models"]:
+            assert abs(np.linalg.det(np.asarray(m["transform"]["matrix"])[:3, :3])) > 1e-9   # invertible, as RCM:196 needs
+    assert counts == {"Glass Balls": 17, "Glass Dragon": 11, "Sphere Refract": 10, "Splash": 8, "Text": 18}
+    d, _ = pkg.unityscene.load_unity_scene(os.path.join(REF_SCENES, "Glass Balls.unity"), stand_ins=STAND_INS)
+    with open(os.path.join(os.path.dirname(HERE), "ray-tracing_amd", "scenes_data", "glass_balls.json")) as f:
+        kept = json.load(f)
+    assert [m["name"] for m in kept["models"]] == [m["name"] for m in d["models"]]
+    for a, b in zip(kept["models"], d["models"]):
+        assert a["mesh"] == b["mesh"] and a["material"] == b["material"]
+        assert np.array_equal(np.asarray(a["transform"]["matrix"]), np.asarray(b["transform"]["matrix"]))
+    assert kept["settings"] == d["settings"] and kept["camera"] == d["camera"]
