@@ -1,5 +1,5 @@
 """Host BVH build: rt_build_bvh_mt at several thread counts vs the literal single-thread restatement (oracle)."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package(); api = pkg.load_library(); orc = g.load_oracle()

@@ -11,7 +11,7 @@ engine or are missing on disk need `--stand-in NAME=SPEC` (SPEC: cube | quad | r
 icosphere:SUBDIV[:DISPLACEMENT_SEED[:RADIUS]] | a JSON mesh spec); a stand-in has to have the
 asset's native size, the scene only stores the Transform on top of it.
 """
-import argparse, json, os, sys, time
+import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 
