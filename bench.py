@@ -268,7 +268,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "rt_trace_kernel<false>",
+                "kernel": "rt_trace_kernel<false, *> (whole-frame launches of the roofline pass; the two half-frame "
+                          "launches per step of the timed pass run the same code as rt_trace_half_kernel)",
                 "algorithmic_bytes_per_launch": my_bytes, "avg_launch_ms": my_ms,
                 "note": "algorithmic bytes = the reference loop's loads for the counted work (SURVEY.md 8(d)); "
                         "the scene is cache/SGPR resident, so frac can exceed what HBM itself delivers. "

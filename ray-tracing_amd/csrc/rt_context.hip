@@ -831,6 +831,9 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
     a.stackEntries = ctx->stackEntries;
     void (*kern)(const KArgs) = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_kernel<true, true> : rtk::rt_trace_kernel<false, true>)
                                                : (ctx->stats ? rtk::rt_trace_kernel<true, false> : rtk::rt_trace_kernel<false, false>);
+    /* the same code under a second name for the two-launches-per-frame form (see rt_kernels.h) */
+    void (*kernHalf)(const KArgs) = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_half_kernel<true, true> : rtk::rt_trace_half_kernel<false, true>)
+                                                   : (ctx->stats ? rtk::rt_trace_half_kernel<true, false> : rtk::rt_trace_half_kernel<false, false>);
     const int variant = (ctx->flatScene ? 2 : 0) + (ctx->stats ? 1 : 0);
     if (ctx->occBytes[variant] != stackBytes + 1) { /* occupancy query cached per (variant, LDS bytes) */
         int perCU = 0;
@@ -895,7 +898,7 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         a.queueStart = parts == 2 ? 1 : 0;
         a.tileQueueBase = ctx->tileQueueNext[p] - (a.queueStart ? 0ull : (unsigned long long)grid);
         if (ctx->verbose) fprintf(stderr, "[raytrace_hip] launch variant=%d part=%d/%d tiles=%d grid=%d perCU=%d lds=%zu\n", variant, p, parts, partTiles, grid, ctx->occPerCU[variant], stackBytes);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(RT_WAVE), stackBytes, p == 0 ? ctx->stream : ctx->sideStream, a);
+        hipLaunchKernelGGL(parts == 2 ? kernHalf : kern, dim3(grid), dim3(RT_WAVE), stackBytes, p == 0 ? ctx->stream : ctx->sideStream, a);
         HIP_TRY(ctx, hipGetLastError()); /* a refused launch ran no wave: the device counter did not move */
         /* every tile not taken by blockIdx is one successful fetch, and each of the grid waves overshoots once */
         ctx->tileQueueNext[p] += (unsigned long long)partTiles + (a.queueStart ? (unsigned long long)grid : 0ull);

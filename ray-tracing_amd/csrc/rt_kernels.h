@@ -614,7 +614,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
  * BVH of the scene (dynamic shared memory).
  * ------------------------------------------------------------------------- */
 template <bool STATS, bool FLAT>
-__global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kernel(const KArgs a)
+__device__ __forceinline__ void trace_body(const KArgs& a)
 {
     extern __shared__ uint32_t s_stack[];
     const int lane = threadIdx.x;
@@ -902,6 +902,22 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kerne
     } else if (lane == 0) {
         atomicAdd(slot + 0, (unsigned long long)segSum);
     }
+}
+
+/* The kernel, under two names: rt_trace_kernel is a launch that renders a whole frame (or batch of
+ * frames) of this context's rows; rt_trace_half_kernel is one of the two launches a frame is split
+ * into while the context runs on its own streams (rt_context.hip, launch_frames) — the same code, so
+ * that profilers list the two kinds of dispatch, whose durations mean different things (the halves
+ * overlap in time), separately. */
+template <bool STATS, bool FLAT>
+__global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kernel(const KArgs a)
+{
+    trace_body<STATS, FLAT>(a);
+}
+template <bool STATS, bool FLAT>
+__global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_half_kernel(const KArgs a)
+{
+    trace_body<STATS, FLAT>(a);
 }
 
 /* ---- test hooks (rt_debug_*): the same device functions, one ray / value per lane */
