@@ -180,13 +180,7 @@ int rt_create(int device_id, RtContext** out)
         ctx->stream = ctx->ownStream;
         HIP_TRY(ctx, hipMalloc(&ctx->dCounters, sizeof(unsigned long long) * RT_COUNTER_SLOTS * RT_COUNTER_FIELDS));
         HIP_TRY(ctx, hipMemset(ctx->dCounters, 0, sizeof(unsigned long long) * RT_COUNTER_SLOTS * RT_COUNTER_FIELDS));
-        {   /* Higher dispatch priority than the main stream: when kernels of both streams wait for
-             * slots, the side stream's workgroups go first, which makes the two streams take turns
-             * from the first pair of launches on instead of starting — and draining — in step. */
-            int prLeast = 0, prGreatest = 0;
-            HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest));
-            HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->sideStream, hipStreamNonBlocking, prGreatest));
-        }
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->sideStream, hipStreamNonBlocking)); /* (a higher priority for it measured no different) */
         HIP_TRY(ctx, hipMalloc(&ctx->dTileQueue, 2 * sizeof(unsigned long long)));
         HIP_TRY(ctx, hipMemset(ctx->dTileQueue, 0, 2 * sizeof(unsigned long long)));
         HIP_TRY(ctx, hipEventCreate(&ctx->evStart));
