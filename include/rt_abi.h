@@ -262,7 +262,11 @@ int rt_get_counters(RtContext* ctx, RtCounters* out); /* synchronises */
 /* BVH.cs:26-318: builds the reference-shaped flat BVH of one mesh.
  * verts/normals: n_verts*3 floats; indices: n_indices ints (3 per triangle).
  * out_nodes must hold >= 2*max(1,n_indices/3) nodes, out_tris n_indices/3
- * triangles. Pure host code (no device needed). */
+ * triangles. Pure host code (no device needed).
+ * Returns RT_ERR_SCENE (nothing written to out_nodes, *out_n_nodes = 0) for input whose
+ * reference-shaped tree would be malformed: coordinates so large that every split cost
+ * overflows make BVH.cs peel off empty children (0-triangle leaves, which the shader reads as
+ * inner nodes, RC:246) and more nodes than that capacity. */
 int rt_build_bvh(const float* verts, const float* normals, int n_verts,
                  const int32_t* indices, int n_indices, int quality,
                  RtBVHNode* out_nodes, int* out_n_nodes,

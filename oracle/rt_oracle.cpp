@@ -52,6 +52,13 @@ struct Counters {
     }
 };
 
+/* Optional per-thread log of the work one pixel does, as a byte stream (tools/sched_sim2.py models
+ * the kernel's scheduling on it; not a reference feature):
+ *   'R' camera ray | 'S' segment start | 'A' model entered | 'B' inner step | 'C' n = leaf with n tests |
+ *   'K' miss (sky) | 'O' opaque hit | 'G' glass hit | 'E' path ended */
+static thread_local std::vector<uint8_t>* g_schedTrace = nullptr;
+static inline void sched_tok(uint8_t t) { if (g_schedTrace) g_schedTrace->push_back(t); }
+
 struct Ray { /* RC:35-47 */
     float3 pos, dir, invDir, transmittance;
     int bounceCount;
@@ -188,6 +195,7 @@ static TriangleHitInfo RayTriangleBVH(const Scene& sc, const Ray& ray, float ray
 
         if (isLeaf) {
             stats.leafSteps++;
+            sched_tok('C'); sched_tok((uint8_t)(node.triangleCount > 255 ? 255 : node.triangleCount));
             for (int i = 0; i < node.triangleCount; i++) {
                 const RtTriangle& tri = sc.triangles[triOffset + node.startIndex + i];
                 TriangleHitInfo triHitInfo = RayTriangle(ray, tri, cullBackface);
@@ -199,6 +207,7 @@ static TriangleHitInfo RayTriangleBVH(const Scene& sc, const Ray& ray, float ray
             }
         } else {
             stats.innerSteps++;
+            sched_tok('B');
             int childIndexA = nodeOffset + node.startIndex + 0;
             int childIndexB = nodeOffset + node.startIndex + 1;
             const RtBVHNode& childA = sc.nodes[childIndexA];
@@ -262,6 +271,7 @@ static ModelHitInfo CalculateRayCollision(const Scene& sc, const Ray& worldRay, 
     memset(&result, 0, sizeof(result)); /* Q6: didHit treated as false */
     result.dst = RT_INF;
     stats.segments++;
+    sched_tok('S');
 
     /* Extension S1, hooked at the commented-out call RC:341: analytic spheres are
      * tested first, in buffer order, strict '<' keeps the first of equal hits. */
@@ -282,6 +292,7 @@ static ModelHitInfo CalculateRayCollision(const Scene& sc, const Ray& worldRay, 
     for (size_t i = 0; i < sc.models.size(); i++) {
         const RtModel& model = sc.models[i];
         stats.modelVisits++;
+        sched_tok('A');
         /* RC:351-353 */
         localRay.pos = rt_mul_point(model.worldToLocal, worldRay.pos, 1);
         localRay.dir = rt_mul_point(model.worldToLocal, worldRay.dir, 0);
@@ -393,10 +404,12 @@ static float3 Trace(const Scene& sc, const RtParams& P, Ray initialRay, uint32_t
             if (P.useSky) {
                 totalLight = totalLight + ray.transmittance * GetEnvironmentLight(P, ray.dir);
             }
+            sched_tok('K');
             break;
         }
 
         const RtMaterial& material = hit.material;
+        sched_tok(material.flag == RT_MATERIAL_GLASS ? 'G' : 'O');
 
         if (material.flag == RT_MATERIAL_GLASS) {
             /* RC:502: exp(-hit.dst * absorption.rgb * absorptionStrength) */
@@ -468,6 +481,7 @@ static float3 RayTracePixel(const Scene& sc, const RtParams& P, float2 uv, uint3
         float3 rayDir = rt_normalize(jitteredFocusPoint - rayOrigin);
 
         Ray ray = CreateRay(rayOrigin, rayDir, rt_v3s(1), 0);
+        sched_tok('R');
         totalIncomingLight = totalIncomingLight + Trace(sc, P, ray, &rngState, stats);
     }
     return totalIncomingLight / (float)P.numRaysPerPixel;
@@ -929,6 +943,13 @@ int oracle_build_bvh(const float* verts, const float* normals, int n_verts, cons
             t.normC[k] = normals[3 * indices[base + 2] + k];
         }
     }
+    /* out_nodes holds 2*max(1,ntri) nodes (rt_abi.h).  BVH.cs itself would go on (List<Node>) and emit a
+     * tree with empty leaves when every split cost overflows — malformed for the shader (RC:246); both
+     * builders refuse it the same way. */
+    if (b.nodes.size() > 2 * (size_t)(ntri > 0 ? ntri : 1) || (ntri > 0 && b.stats.leafMinTriCount == 0)) {
+        *out_n_nodes = 0;
+        return RT_ERR_SCENE;
+    }
     memcpy(out_nodes, b.nodes.data(), b.nodes.size() * sizeof(RtBVHNode));
     *out_n_nodes = (int)b.nodes.size();
     if (out_stats) {
@@ -1056,6 +1077,18 @@ void oracle_trace_pixel(OracleContext* ctx, int x, int y, int frame, float out[3
     float2 uv = {rt_div((float)(uint32_t)x, (float)(uint32_t)ctx->W - 1.0f), rt_div((float)(uint32_t)y, (float)(uint32_t)ctx->H - 1.0f)};
     float3 col = RayTracePixel(ctx->scene, P, uv, (uint32_t)ctx->W, (uint32_t)ctx->H, c);
     out[0] = col.x; out[1] = col.y; out[2] = col.z;
+}
+/* oracle_trace_pixel with the work log switched on; returns the log's length (bytes copied: min(len, cap)). */
+int oracle_trace_pixel_schedule(OracleContext* ctx, int x, int y, int frame, uint8_t* buf, int cap)
+{
+    std::vector<uint8_t> log;
+    g_schedTrace = &log;
+    float out[3];
+    oracle_trace_pixel(ctx, x, y, frame, out);
+    g_schedTrace = nullptr;
+    int n = (int)log.size();
+    if (buf) memcpy(buf, log.data(), (size_t)(n < cap ? n : cap));
+    return n;
 }
 /* rt_math.h primitives over arrays. op: 0 log 1 exp 2 sin 3 cos 4 sqrt 5 pow(x,y) 6 div(x/y) 7 smoothstep(0,y,x) */
 void oracle_math_eval(int op, const float* x, const float* y, float* out, int n)

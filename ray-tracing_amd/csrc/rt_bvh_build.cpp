@@ -402,7 +402,7 @@ int build(const float* verts, const float* normals, int n_verts, const int32_t* 
         const int grain = 4096;
         const size_t maxTop = (size_t)ntri / 1024 * 4 + 64;
         std::vector<TopNode> top;
-        top.reserve(maxTop); /* never reallocates: other threads hold indices into it */
+        top.reserve(maxTop + 2 * (size_t)threads); /* indices, never references, are held across the lock */
         std::vector<Task> tasks;
         tasks.reserve(maxTop);
         TopNode r;
@@ -423,8 +423,15 @@ int build(const float* verts, const float* normals, int n_verts, const int32_t* 
                     i = queue.back();
                     queue.pop_back();
                 }
-                const TopNode tn = top[i];
-                if (tn.count <= grain || top.size() + 2 > maxTop) {
+                /* every access to `top` happens under the mutex (push_back may reallocate it) */
+                TopNode tn;
+                bool listFull;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    tn = top[i];
+                    listFull = top.size() + 2 * (size_t)threads > maxTop; /* room for every worker's two children */
+                }
+                if (tn.count <= grain || listFull) {
                     /* build into thread-local containers (no false sharing between neighbouring tasks) */
                     std::vector<RtBVHNode> local;
                     std::vector<uint8_t> inner;
@@ -528,6 +535,18 @@ int build(const float* verts, const float* normals, int n_verts, const int32_t* 
             }
         }
     });
+    /* A well-formed tree has at most 2*ntri-1 nodes.  The reference's (axis 0, pos 0) fallback split
+     * (BVH:213-217) can peel off EMPTY children when every candidate cost is inf/NaN (coordinates
+     * around 1e19 and beyond): such a tree has 0-triangle "leaves" the shader would read as inner
+     * nodes (RC:246) and more nodes than the documented capacity of out_nodes — refuse it. */
+    if (nodes.size() > 2 * (size_t)(ntri > 0 ? ntri : 1)) {
+        *out_n_nodes = 0;
+        return RT_ERR_SCENE;
+    }
+    if (ntri > 0 && st.leafMinTriCount == 0) { /* an empty leaf, even if the node count stayed in bounds */
+        *out_n_nodes = 0;
+        return RT_ERR_SCENE;
+    }
     memcpy(out_nodes, nodes.data(), nodes.size() * sizeof(RtBVHNode));
     *out_n_nodes = (int)nodes.size();
     if (out_stats) {

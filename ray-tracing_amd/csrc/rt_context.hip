@@ -482,6 +482,7 @@ struct SceneBuilder {
     std::vector<uint32_t> bigLeaves;
     std::vector<int32_t> pairOfFirstChild; /* absolute first-child node index -> pair id, -1 unseen, -2 in progress */
     std::vector<int32_t> pairDepth;        /* height of the subtree below pair (levels) */
+    std::vector<long long> pairLeafEnd;    /* largest startIndex + triangleCount of the leaves below pair (mesh-relative) */
     std::string error;
 
     /* code of a leaf node whose triangles are [start, start+count) relative to triOffset */
@@ -508,11 +509,12 @@ struct SceneBuilder {
      * Returns its code and height (leaf = 0). Iterative post-order walk, memoised per sibling pair. */
     bool convert(int nodeOffset, int triOffset, int absRoot, uint32_t* codeOut, int* heightOut)
     {
-        struct Frame { int abs; int stage; int firstChild; uint32_t codeA, codeB; int hA, hB; };
+        struct Frame { int abs; int stage; int firstChild; uint32_t codeA, codeB; int hA, hB; long long endA; };
         std::vector<Frame> stack;
-        stack.push_back({absRoot, 0, -1, 0, 0, 0, 0});
+        stack.push_back({absRoot, 0, -1, 0, 0, 0, 0, 0});
         uint32_t retCode = 0;
         int retHeight = 0;
+        long long retEnd = 0; /* largest leaf end (mesh-relative) of the subtree just returned */
         while (!stack.empty()) {
             Frame& f = stack.back();
             const RtBVHNode& n = nodes[f.abs];
@@ -520,6 +522,7 @@ struct SceneBuilder {
                 if (n.triangleCount > 0) { /* leaf — RC:246 */
                     if (!leaf_code(n, triOffset, &retCode)) return false;
                     retHeight = 0;
+                    retEnd = (long long)n.startIndex + n.triangleCount;
                     stack.pop_back();
                     continue;
                 }
@@ -529,8 +532,12 @@ struct SceneBuilder {
                 int known = pairOfFirstChild[f.firstChild];
                 if (known == -2) { error = "cycle in BVH node graph"; return false; }
                 if (known >= 0) {
+                    /* converted for an earlier model that shares these nodes: its leaves were range-checked
+                     * against THAT model's triOffset, so check this one's against the subtree's largest leaf end */
+                    if ((long long)triOffset + pairLeafEnd[known] > nTris) { error = "leaf triangle range out of bounds"; return false; }
                     retCode = (uint32_t)known;
                     retHeight = pairDepth[known];
+                    retEnd = pairLeafEnd[known];
                     stack.pop_back();
                     continue;
                 }
@@ -538,15 +545,16 @@ struct SceneBuilder {
                 pairOfFirstChild[f.firstChild] = -2;
                 f.stage = 1;
                 int child = f.firstChild;
-                stack.push_back({child, 0, -1, 0, 0, 0, 0});
+                stack.push_back({child, 0, -1, 0, 0, 0, 0, 0});
                 continue;
             }
             if (f.stage == 1) {
                 f.codeA = retCode;
                 f.hA = retHeight;
+                f.endA = retEnd;
                 f.stage = 2;
                 int child = f.firstChild + 1;
-                stack.push_back({child, 0, -1, 0, 0, 0, 0});
+                stack.push_back({child, 0, -1, 0, 0, 0, 0, 0});
                 continue;
             }
             /* stage 2: both children done */
@@ -564,9 +572,11 @@ struct SceneBuilder {
             pairs.push_back(p);
             int h = 1 + (f.hA > f.hB ? f.hA : f.hB);
             pairDepth.push_back(h);
+            pairLeafEnd.push_back(f.endA > retEnd ? f.endA : retEnd);
             pairOfFirstChild[f.firstChild] = id;
             retCode = (uint32_t)id;
             retHeight = h;
+            retEnd = pairLeafEnd.back();
             stack.pop_back();
         }
         *codeOut = retCode;

@@ -47,6 +47,32 @@ def test_empty_mesh_builds_a_single_empty_leaf(pkg, api, orc):
     assert n1[0]["triangleCount"] == 0 and n1.tobytes() == n2.tobytes()
 
 
+def test_overflow_scale_coordinates_are_refused_not_overrun(pkg, api, orc):
+    """Coordinates around 1e19+: node areas overflow to inf, every split cost is inf, and BVH.cs's
+    (axis 0, pos 0) fallback peels off an empty child per level down to MaxDepth — 65 nodes for 3
+    triangles against a documented out_nodes capacity of 6, with 0-triangle leaves the shader would
+    read as inner nodes.  Both builders must refuse (RT_ERR_SCENE) without writing past the capacity."""
+    rng = np.random.default_rng(3)
+    v = (rng.uniform(-1, 1, (9, 3)) * 3e19).astype(np.float32)
+    mesh = pkg.meshes.Mesh(v, np.tile([[0, 1, 0]], (9, 1)), np.arange(9, dtype=np.int32), "huge")
+    for lib in (api, orc):
+        with pytest.raises(pkg.abi.RtError) as e:
+            lib.build_bvh_arrays(mesh.vertices, mesh.normals, mesh.triangles, pkg.abi.BVH_QUALITY_HIGH)
+        assert e.value.status == pkg.abi.RT_ERR_SCENE
+        try:  # Low quality: a tree within the capacity, or the same refusal
+            n, _, st = lib.build_bvh_arrays(mesh.vertices, mesh.normals, mesh.triangles, pkg.abi.BVH_QUALITY_LOW)
+            assert len(n) <= 6 and st["leafMinTriCount"] > 0
+        except pkg.abi.RtError as err:
+            assert err.status == pkg.abi.RT_ERR_SCENE
+    if hasattr(api, "build_bvh_arrays_mt"):
+        with pytest.raises(pkg.abi.RtError):
+            api.build_bvh_arrays_mt(mesh.vertices, mesh.normals, mesh.triangles, 1, 4)
+    # the same mesh at a sane scale builds
+    small = pkg.meshes.Mesh(v / np.float32(3e19), mesh.normals, mesh.triangles, "small")
+    (n1, _, _), (n2, _, _) = both(api, orc, small, 1)
+    assert n1.tobytes() == n2.tobytes() and len(n1) <= 6
+
+
 def test_tree_structure_invariants(pkg, api):
     """What the kernel relies on: children adjacent (BVH:161-162), inner root keeps
     triangleCount -1 (BVH:61), inner non-root 0, leaves partition the triangle range,
