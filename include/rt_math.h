@@ -57,7 +57,15 @@ RT_HD float rt_lerp(float a, float b, float t) { return a + (b - a) * t; }
  * form used here keeps that shape with a correctly rounded reciprocal, so a reciprocal of
  * a wave-uniform or repeated denominator is computed once. */
 RT_HD float rt_rcp(float x) { return 1.0f / x; }
+#ifndef RT_MATH_IEEE
 RT_HD float rt_div(float a, float b) { return a * rt_rcp(b); }
+#else
+/* RT_MATH_IEEE: the alternative reading of what HLSL leaves open — '/' as a correctly rounded
+ * IEEE divide, normalize as v / sqrt(dot), smoothstep with its own divide.  Built for the ORACLE
+ * only (oracle/liboracle_ieee.so); tests/test_contract_bracket.py measures how far the two readings
+ * are apart (far below the Monte-Carlo error), bracketing the contract the reference cannot pin. */
+RT_HD float rt_div(float a, float b) { return a / b; }
+#endif
 /* HLSL smoothstep(a,b,x) = saturate((x-a)/(b-a)) then Hermite; every call site of the shader
  * passes literal edges (RC:175-176), for which the compiler folds 1/(b-a) into a constant:
  * inv_range is that constant (correctly rounded). */
@@ -65,6 +73,16 @@ RT_HD float rt_smoothstep(float a, float inv_range, float x)
 {
     float t = rt_saturate((x - a) * inv_range);
     return t * t * (3.0f - 2.0f * t);
+}
+/* the shader's form, smoothstep(a, b, x) with literal edges: 1/(b-a) is the folded constant above */
+RT_HD float rt_smoothstep_edges(float a, float b, float x)
+{
+#ifndef RT_MATH_IEEE
+    return rt_smoothstep(a, 1.0f / (b - a), x);
+#else
+    float t = rt_saturate((x - a) / (b - a));
+    return t * t * (3.0f - 2.0f * t);
+#endif
 }
 
 /* ------------------------------------------------------------------- logf */
@@ -232,7 +250,11 @@ RT_HD rt_f3 operator*(rt_f3 a, rt_f3 b) { return rt_v3(a.x * b.x, a.y * b.y, a.z
 RT_HD rt_f3 operator*(rt_f3 a, float s) { return rt_v3(a.x * s, a.y * s, a.z * s); }
 RT_HD rt_f3 operator*(float s, rt_f3 a) { return rt_v3(s * a.x, s * a.y, s * a.z); }
 /* float3 / scalar: one reciprocal, three multiplies (see rt_div) */
+#ifndef RT_MATH_IEEE
 RT_HD rt_f3 operator/(rt_f3 a, float s) { float r = rt_rcp(s); return rt_v3(a.x * r, a.y * r, a.z * r); }
+#else
+RT_HD rt_f3 operator/(rt_f3 a, float s) { return rt_v3(a.x / s, a.y / s, a.z / s); }
+#endif
 RT_HD rt_f3 operator-(rt_f3 a) { return rt_v3(-a.x, -a.y, -a.z); }
 /* HLSL dot(): left-to-right sum of products */
 RT_HD float rt_dot(rt_f3 a, rt_f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
@@ -261,7 +283,11 @@ RT_HD float rt_rsqrt(float x)
 /* HLSL normalize(): DXC lowers it to v * rsqrt(dot(v,v)) — followed here with
  * the strict rsqrt above (one sqrt, one divide, three multiplies).  A zero
  * vector gives NaNs (0 * inf), like the shader. */
+#ifndef RT_MATH_IEEE
 RT_HD rt_f3 rt_normalize(rt_f3 v) { return v * rt_rsqrt(rt_dot(v, v)); }
+#else
+RT_HD rt_f3 rt_normalize(rt_f3 v) { return v / rt_sqrt(rt_dot(v, v)); }
+#endif
 RT_HD rt_f3 rt_lerp3(rt_f3 a, rt_f3 b, float t)
 {
     return rt_v3(rt_lerp(a.x, b.x, t), rt_lerp(a.y, b.y, t), rt_lerp(a.z, b.z, t));

@@ -8,21 +8,24 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 
-def build(force=False):
-    if force or not os.path.exists(LIB_PATH) or any(
-            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(LIB_PATH)
+def build(force=False, variant=""):
+    """variant "" = the contract of include/rt_math.h; "ieee" = the RT_MATH_IEEE reading (bracket tests only)."""
+    name = "liboracle_ieee.so" if variant == "ieee" else "liboracle.so"
+    path = os.path.join(_HERE, name)
+    if force or not os.path.exists(path) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(path)
             for f in ("rt_oracle.cpp", "../include/rt_math.h", "../include/rt_abi.h")):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
-    return LIB_PATH
+        subprocess.check_call(["make", "-C", _HERE, "-B", name], stdout=subprocess.DEVNULL)
+    return path
 
 
-def load(pkg):
+def load(pkg, variant=""):
     """Returns (api, tracer_factory) for the oracle, bound with the package's generic CApi."""
     abi = pkg.abi
 
     class OracleApi(abi.CApi):
         def __init__(self):
-            super().__init__(build(), "oracle_")
+            super().__init__(build(variant=variant), "oracle_")
             L = self.lib
             self._bind("create", C.c_int, [C.POINTER(C.c_void_p)])
             self._bind("set_threads", C.c_int, [C.c_void_p, C.c_int])

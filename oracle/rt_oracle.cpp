@@ -119,8 +119,8 @@ static float3 GetEnvironmentLight(const RtParams& P, float3 dir)
     const float3 SkyColourHorizon = rt_v3(1, 1, 1);
     const float3 SkyColourZenith = rt_v3(0.08f, 0.37f, 0.73f);
 
-    float skyGradientT = rt_pow(rt_smoothstep(0, 1.0f / 0.4f, dir.y), 0.35f);
-    float groundToSkyT = rt_smoothstep(-0.01f, 1.0f / 0.01f, dir.y);
+    float skyGradientT = rt_pow(rt_smoothstep_edges(0, 0.4f, dir.y), 0.35f);
+    float groundToSkyT = rt_smoothstep_edges(-0.01f, 0, dir.y);
     float3 skyGradient = rt_lerp3(SkyColourHorizon, SkyColourZenith, skyGradientT);
     float s = rt_div(1000 * 1, P.sunFocus); /* RC:178: (1000*1)/SunFocus */
     float sun = rt_pow(rt_max(0, rt_dot(dir, f3(P.dirToSun))), s) * P.sunIntensity;
@@ -1109,6 +1109,10 @@ void oracle_math_eval(int op, const float* x, const float* y, float* out, int n)
         }
     }
 }
+#ifndef RT_MATH_IEEE
 const char* oracle_version(void) { return "rt_oracle (CPU restatement, test infrastructure) abi=1"; }
+#else
+const char* oracle_version(void) { return "rt_oracle (CPU restatement, test infrastructure) abi=1 RT_MATH_IEEE"; }
+#endif
 
 } /* extern "C" */

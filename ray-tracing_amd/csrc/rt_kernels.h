@@ -136,8 +136,8 @@ __device__ __forceinline__ rt_f2 rand_circle(uint32_t* state)
 template <class Args>
 __device__ __forceinline__ rt_f3 environment_light(const Args& a, rt_f3 dir)
 {
-    float skyGradientT = rt_pow(rt_smoothstep(0.0f, 1.0f / 0.4f, dir.y), 0.35f);
-    float groundToSkyT = rt_smoothstep(-0.01f, 1.0f / 0.01f, dir.y);
+    float skyGradientT = rt_pow(rt_smoothstep_edges(0.0f, 0.4f, dir.y), 0.35f);
+    float groundToSkyT = rt_smoothstep_edges(-0.01f, 0.0f, dir.y);
     rt_f3 skyGradient = rt_lerp3(rt_v3(1, 1, 1), rt_v3(0.08f, 0.37f, 0.73f), skyGradientT);
     float s = rt_div(1000 * 1, a.sunFocus);
     rt_f3 toSun = rt_v3(a.dirToSun[0], a.dirToSun[1], a.dirToSun[2]);

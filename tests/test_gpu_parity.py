@@ -7,6 +7,8 @@ through size-independent properties: determinism, partition invariance (row-tile
 shards == whole image), batch == repeated single frames, alpha == frame count,
 frame additivity, and a strip-sampled oracle comparison.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -279,6 +281,46 @@ def test_config3_full_size_strip_sample(pkg, api, orc):
     c.close()
     for s in (20, 100):
         assert bits_equal(gpu[s * 8: s * 8 + 8], cpu[s * 8: s * 8 + 8]), s
+
+
+def _strips_against_oracle(pkg, api, orc, cfg, strips):
+    """One full-size frame of a BASELINE configuration on the GPU; 8-row strips of it re-rendered by the
+    oracle (row window) must carry the same bits."""
+    tr = api.create_tracer(0)
+    sc = pkg.scenes.get(cfg)
+    mgr = sc.make_manager(tr, api)
+    mgr.OnEnable(renderSeed=1)
+    mgr.RenderFrame()
+    gpu = tr.read_accumulated()
+    tr.close()
+    assert gpu.shape[:2] == (sc.height, sc.width)
+    c = orc.create_tracer(os.cpu_count() or 8)
+    m2 = pkg.scenes.get(cfg).make_manager(c, orc)
+    m2.OnEnable(renderSeed=1)
+    for s in strips:
+        m2.numAccumulatedFrames = 1
+        m2.SetShaderParams()
+        orc.set_row_window(c.h, s * 8, s * 8 + 8)
+        c.render_frame()
+    cpu = c.read_accumulated()
+    c.close()
+    for s in strips:
+        assert bits_equal(gpu[s * 8: s * 8 + 8], cpu[s * 8: s * 8 + 8]), (cfg, s)
+        assert np.any(gpu[s * 8: s * 8 + 8, :, :3] > 0), (cfg, s)  # not a strip of black
+
+
+def test_config4_full_size_strip_sample(pkg, api, orc):
+    """BASELINE config 4 as benchmarked: 1920x1080, depth of field on, the whole 81,920-triangle mesh."""
+    sc = pkg.scenes.get(4)
+    assert (sc.width, sc.height) == (1920, 1080) and sc.settings["defocusStrength"] > 0 and sc.unique_triangles() > 81920
+    _strips_against_oracle(pkg, api, orc, 4, (40, 67))
+
+
+def test_config5_full_size_strip_sample(pkg, api, orc):
+    """BASELINE config 5 as benchmarked: 3840x2160, 12 bounces, all 983,040 mesh triangles (+ room)."""
+    sc = pkg.scenes.get(5)
+    assert (sc.width, sc.height) == (3840, 2160) and sc.settings["maxBounceCount"] == 12 and sc.unique_triangles() >= 983040
+    _strips_against_oracle(pkg, api, orc, 5, (101, 150))
 
 
 # ------------------------------------------------------------------ scheduling must not change results
