@@ -1,33 +1,43 @@
 #!/usr/bin/env python
 """bench.py — Mrays/s of the path-tracing hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C] [--scaling strong|weak]
 
-Workload = BASELINE.json configs[1]: 1920x1080, 8 spp, 8 bounces, 16 analytic
-spheres + checkered ground quad, sky on (ray_tracing_amd.scenes.config2).  One
-"step" = one frame = one launch of the trace kernel over the whole image (the
-reference's RenderFrame, RayComputeManager.cs:84-95); successive steps are
-successive Frame indices of a progressive render, exactly like the reference.
-Scene and render targets are resident in HBM before the timed region.
+Workload (default) = BASELINE.json configs[1]: 1920x1080, 8 spp, 8 bounces, 16 analytic spheres +
+checkered ground quad, sky on (ray_tracing_amd.scenes.config2).  `--config 5` is the north_star's
+8-GPU case (3840x2160, 12 bounces, 983k triangles).  One "step" = one frame = the reference's Dispatch
+of the whole image (RayComputeManager.cs:84-95); successive steps are successive Frame indices of a
+progressive render.  Scene and render targets are resident in HBM before the timed region.
 
-"rays" = path segments = CalculateRayCollision calls (RayCommon.hlsl:487),
-counted exactly by the kernel.  For N > 1 the image is split into cyclic 8-row
-strips (one process per GPU, no data-path collective); the single RCCL gather
-of the tiles happens at readback, after the timed steps, and is reported
-separately (`gather_ms`).
+"rays" = path segments = CalculateRayCollision calls (RayCommon.hlsl:487), counted exactly by the kernel.
+`value` times K x rt_render_frame (the Dispatch only); `value_with_initframe` times K x the mirror's
+RenderFrame() = InitFrame (UpdateModels + SetShaderParams every frame, RCM:115-124) + Dispatch.
 
-Scaling is WEAK by default: per-GPU work is fixed at 1920x1080 pixels — the image
-area grows with N at the same 16:9 view (N=4 is the north_star's 3840x2160), so
-every rank renders ~2.07 Mpixels of the same scene.  `--scaling strong` keeps the
-1920x1080 image for every N instead (a pixel's 8 samples x 9 segments are one
-serial chain, so a 1/8 image is bounded by that chain).
+N > 1: one process per GPU.  With WORLD_SIZE unset, `python bench.py --gpus N` spawns the N ranks itself
+(torch.distributed.run, 127.0.0.1); under torch.distributed.run it is one rank.  The image is split into
+cyclic 8-row strips (no data-path collective), scaling is STRONG by default (the BASELINE image is fixed,
+each rank renders 1/N of its rows); the one RCCL gather of the accumulation tiles happens at readback,
+after the timed steps, and is reported as `gather_ms`.  `--scaling weak` grows the image with N instead.
+
+roofline (rank 0, N = 1): the kernel is VALU-issue bound, not memory bound, so
+`bound` = "valu": achieved = SQ_INSTS_VALU per launch / average launch time, peak = 256 CU x 4 SIMD x
+2.4 GHz / 2 cycles per wave64 instruction, frac = achieved/peak x lane utilisation
+(SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)).  The counters come from rocprofv3 PMC passes over a
+child run of THIS script in the same invocation (separate passes for the SQ counters, FETCH_SIZE and
+WRITE_SIZE); if rocprofv3 is unavailable the committed profiles/ summary is replayed and labelled so.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
+import shutil
+import socket
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -35,45 +45,245 @@ sys.path.insert(0, ROOT)
 
 import __graft_entry__ as graft  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK = 256 * 4 * 2.4e9 / 2.0          # wave64 VALU instructions / s: 256 CUs x 4 SIMD-32, 2 cycles each
+KERNEL_LIKE = "%rt_trace%kernel<false%"    # the non-stats instantiations (whole-frame and half-frame names)
+
+
+# --------------------------------------------------------------------------- helpers
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) ourselves."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(pkg, scene_id, width, height, min_s=10.0, max_frames=4, threads=1):
-    """The CPU oracle (a port of the reference's loop; ONE thread unless told otherwise) timed on
-    a bounded sample of the same workload: whole frames 1, 2, ... of the same scene at the same
-    resolution until at least `min_s` seconds of wall time are spent."""
+    """The CPU oracle (a port of the reference's loop) on a bounded sample of the same workload: whole
+    frames 1, 2, ... of the same scene at the same resolution until `min_s` seconds are spent.  The
+    single-thread figure is pinned to one core (the `taskset -c <cpu>` of SURVEY.md §8(d))."""
     orc = graft.load_oracle()
-    tr = orc.create_tracer(threads=threads)
-    sc = pkg.scenes.get(scene_id)
-    mgr = sc.make_manager(tr, orc, width, height)
-    mgr.OnEnable(renderSeed=1)
-    tr.reset_counters()
-    t0 = time.perf_counter()
-    frames = 0
-    while frames < max_frames and (frames == 0 or time.perf_counter() - t0 < min_s):
-        mgr.RenderFrame()
-        frames += 1
-    dt = time.perf_counter() - t0
-    c = tr.counters()
-    tr.close()
+    pinned = None
+    old = None
+    if threads == 1 and hasattr(os, "sched_setaffinity"):
+        old = os.sched_getaffinity(0)
+        pinned = min(old)
+        os.sched_setaffinity(0, {pinned})
+    try:
+        tr = orc.create_tracer(threads=threads)
+        sc = pkg.scenes.get(scene_id)
+        mgr = sc.make_manager(tr, orc, width, height)
+        mgr.OnEnable(renderSeed=1)
+        tr.reset_counters()
+        t0 = time.perf_counter()
+        frames = 0
+        while frames < max_frames and (frames == 0 or time.perf_counter() - t0 < min_s):
+            mgr.RenderFrame()
+            frames += 1
+        dt = time.perf_counter() - t0
+        c = tr.counters()
+        tr.close()
+    finally:
+        if old is not None:
+            os.sched_setaffinity(0, old)
     return {
         "value": c["segments"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-        "sample": f"oracle/rt_oracle.cpp (g++ -O2, strict fp32), {threads} thread(s): frames 1..{frames} of the same scene at "
-                  f"{width}x{height} ({c['segments']} segments in {dt:.1f} s)",
+        "sample": f"oracle/rt_oracle.cpp (g++ -O2, strict fp32), {threads} thread(s)"
+                  + (f" pinned to cpu {pinned}" if pinned is not None else "")
+                  + f": frames 1..{frames} of the same scene at {width}x{height} ({c['segments']} segments in {dt:.1f} s)",
         "nproc": os.cpu_count(),
     }
 
 
+def parity_check(pkg, api, dev_index, scene_id, width, height, strips):
+    """In-run parity: frame 1 of the benchmarked scene at the benchmarked size on a fresh context, 8-row
+    strips re-rendered by the oracle — bitwise comparison + per-channel relative L2 of the strips."""
+    import numpy as np
+    tr = api.create_tracer(dev_index)
+    mgr = pkg.scenes.get(scene_id).make_manager(tr, api, width, height)
+    mgr.OnEnable(renderSeed=1)
+    mgr.RenderFrame()
+    gpu = tr.read_accumulated()
+    tr.close()
+    orc = graft.load_oracle()
+    c = orc.create_tracer(min(os.cpu_count() or 1, 16))
+    m2 = pkg.scenes.get(scene_id).make_manager(c, orc, width, height)
+    m2.OnEnable(renderSeed=1)
+    for s in strips:
+        m2.numAccumulatedFrames = 1
+        m2.SetShaderParams()
+        orc.set_row_window(c.h, s * 8, min(height, s * 8 + 8))
+        c.render_frame()
+    cpu = c.read_accumulated()
+    c.close()
+    rows = np.concatenate([np.arange(s * 8, min(height, s * 8 + 8)) for s in strips])
+    a, b = gpu[rows], cpu[rows]
+    ident = bool(np.array_equal(a.view(np.uint32), b.view(np.uint32)))
+    l2 = [float(np.sqrt(np.sum((a[..., k].astype(np.float64) - b[..., k]) ** 2) / max(float(np.sum(b[..., k].astype(np.float64) ** 2)), 1e-300)))
+          for k in range(3)]
+    mx = float(np.max(np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b.astype(np.float64)), 1e-30)))
+    return {"checked_in_this_run": f"frame 1 at {width}x{height}, 8-row strips {list(strips)} vs oracle/ ({len(rows) * width} pixels)",
+            "bit_identical": ident, "rel_l2_per_channel": l2, "max_rel_err": mx}
+
+
+# --------------------------------------------------------------------------- PMC passes (rocprofv3 around a child run)
+def pmc_child(args):
+    """Child of the PMC passes: one kernel per frame on one stream, `steps` frames, nothing else (no torch)."""
+    os.environ["RT_TWO_STREAMS"] = "0"
+    pkg = graft.load_package()
+    api = pkg.load_library()
+    tr = api.create_tracer(0)
+    sc = pkg.scenes.get(args.config)
+    mgr = sc.make_manager(tr, api)
+    mgr.OnEnable(renderSeed=1)
+    for _ in range(args.warmup):
+        mgr.RenderFrame()
+    tr.synchronize()
+    for _ in range(args.steps):
+        tr.render_frame()
+    tr.synchronize()
+    tr.close()
+
+
+def run_pmc_pass(counters, config, steps, warmup, outdir, tag):
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    d = os.path.join(outdir, tag)
+    cmd = [exe, "--pmc"] + counters + ["--kernel-trace", "-d", d, "-o", "pmc", "--",
+                                       sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", str(config),
+                                       "--steps", str(steps), "--warmup", str(warmup)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    except Exception:
+        return None
+    if r.returncode != 0:
+        return None
+    res = {}
+    for db in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
+        cur = sqlite3.connect(db).cursor()
+        q = ("select counter_name, count(*), avg(v) from (select counter_name, dispatch_id, sum(value) as v from counters_collection "
+             f"where kernel_name like '{KERNEL_LIKE}' group by counter_name, dispatch_id) group by counter_name")
+        try:
+            for name, n, avg in cur.execute(q):
+                res[name] = {"n": n, "avg": avg}
+            # only the last `steps` dispatches are the measured ones, but warmup frames do the same work: averaged together
+        except sqlite3.Error:
+            return None
+    return res or None
+
+
+def collect_pmc(config, steps, warmup, with_traffic):
+    """SQ pass (+ FETCH_SIZE and WRITE_SIZE passes) over child runs of this script; None if rocprofv3 cannot run."""
+    out = tempfile.mkdtemp(prefix="rt_pmc_", dir="/tmp")
+    try:
+        sq = run_pmc_pass(["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES"], config, steps, warmup, out, "sq")
+        if not sq or "SQ_INSTS_VALU" not in sq:
+            return None
+        r = {"valu_insts_per_launch": sq["SQ_INSTS_VALU"]["avg"],
+             "lane_util": sq["SQ_THREAD_CYCLES_VALU"]["avg"] / (64.0 * sq["SQ_ACTIVE_INST_VALU"]["avg"]),
+             "launches_sampled": sq["SQ_INSTS_VALU"]["n"]}
+        if with_traffic:
+            rd = run_pmc_pass(["FETCH_SIZE"], config, steps, warmup, out, "rd")
+            wr = run_pmc_pass(["WRITE_SIZE"], config, steps, warmup, out, "wr")
+            if rd and wr and "FETCH_SIZE" in rd and "WRITE_SIZE" in wr:
+                # MI355X_MICROARCH.md §HBM: KiB units; gfx950 FETCH_SIZE counts wide coalesced reads at 1/2 -> x2; WRITE_SIZE as is
+                r["hbm_read_bytes"] = rd["FETCH_SIZE"]["avg"] * 1024 * 2
+                r["hbm_write_bytes"] = wr["WRITE_SIZE"]["avg"] * 1024
+        return r
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def replayed_pmc(config):
+    prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if not os.path.exists(prof):
+        return None
+    with open(prof) as f:
+        p = json.load(f).get(f"config{config}_n1")
+    if not p:
+        return None
+    return {"valu_insts_per_launch": p["valu_insts"], "lane_util": p["valu_lane_utilisation"],
+            "hbm_read_bytes": p.get("read_bytes"), "hbm_write_bytes": p.get("write_bytes"),
+            "replayed_from": "profiles/pmc_summary.json (" + p.get("source", "?") + ")"}
+
+
+def single_launch_ms(pkg, api, dev_index, scene_id, W, H, steps, warmup, partition=None):
+    """Average duration of ONE kernel per frame on one stream (RT_TWO_STREAMS=0), HIP events on the launch stream."""
+    prev = os.environ.get("RT_TWO_STREAMS")
+    os.environ["RT_TWO_STREAMS"] = "0"
+    try:
+        t = api.create_tracer(dev_index)
+    finally:
+        if prev is None:
+            del os.environ["RT_TWO_STREAMS"]
+        else:
+            os.environ["RT_TWO_STREAMS"] = prev
+    if partition:
+        t.set_partition(*partition)
+    sc = pkg.scenes.get(scene_id)
+    m = sc.make_manager(t, api, W, H)
+    m.OnEnable(renderSeed=1)
+    for _ in range(warmup):
+        m.RenderFrame()
+    t.synchronize()
+    t.reset_counters()
+    t.timer_begin()
+    for _ in range(steps):
+        t.render_frame()
+    t.timer_end()
+    c = t.counters()
+    t.close()
+    return c["gpuMs"] / steps, c["segments"]
+
+
+def valu_roofline(pmc, launch_ms, segments_per_launch):
+    achieved = pmc["valu_insts_per_launch"] / (launch_ms * 1e-3)
+    r = {"bound": "valu", "achieved": achieved / 1e9, "peak": VALU_PEAK / 1e9, "unit": "Gwave-inst/s",
+         "lane_util": pmc["lane_util"], "frac": achieved / VALU_PEAK * pmc["lane_util"],
+         "valu_busy": achieved / VALU_PEAK, "valu_insts_per_launch": pmc["valu_insts_per_launch"], "avg_launch_ms": launch_ms,
+         "valu_insts_per_segment": pmc["valu_insts_per_launch"] / max(1, segments_per_launch),
+         "counters": "replayed: " + pmc["replayed_from"] if "replayed_from" in pmc else
+                     f"rocprofv3 --pmc passes over a child run of this script, in this invocation ({pmc.get('launches_sampled')} launches)"}
+    if pmc.get("hbm_read_bytes") is not None and pmc.get("hbm_write_bytes") is not None:
+        r["traffic"] = pmc["hbm_read_bytes"] + pmc["hbm_write_bytes"]
+        r["hbm_physical"] = {"bytes_per_launch": r["traffic"], "GBps": r["traffic"] / (launch_ms * 1e-3) / 1e9,
+                             "frac_of_8TBps": r["traffic"] / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    else:
+        r["traffic"] = None
+    return r
+
+
+# --------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, help="scene id (default 2 = the headline workload)")
+    ap.add_argument("--config", type=int, default=2, help="scene id (default 2 = the headline workload; 5 = the 8-GPU 3840x2160 case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the informational rt_render_frames(K) pass (profile runs)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes (roofline counters are then replayed from profiles/)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the BVH-workload roofline block (configs 3 and 4)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.pmc_child:
+        return pmc_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -82,7 +292,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     # Test hooks (single-GPU boxes): RT_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 and
@@ -144,6 +354,18 @@ def main():
     elapsed = t1 - t0
     segments = timed["segments"]
 
+    # ---- the same K frames through the host mirror's RenderFrame(): InitFrame + Dispatch per frame (RCM:84-95)
+    mgr.numAccumulatedFrames = first_frame
+    tracer.reset_counters()
+    barrier()
+    i0 = time.perf_counter()
+    for _ in range(args.steps):
+        mgr.RenderFrame()
+    barrier()
+    init_elapsed = time.perf_counter() - i0
+    init_segments = tracer.counters()["segments"]
+    assert init_segments == segments, (init_segments, segments)
+
     # ---- untimed replay of the same K frames with the detailed counters on
     # (identical work: the frame index and seed decide every ray) -> algorithmic bytes
     tracer.reset_counters()
@@ -171,35 +393,19 @@ def main():
                    "value": tracer.counters()["segments"] / batched_elapsed / 1e6, "unit": "Mrays/s",
                    "ms_per_frame": batched_elapsed / args.steps * 1e3}
 
-    # ---- roofline pass (rank 0): the timed pass above launches every frame as two kernels on two
+    # ---- roofline pass (rank 0): the timed pass above may launch every frame as two kernels on two
     # streams that overlap in time, so "duration of one launch" is not defined there.  The same K
     # frames are rendered once more by a context restricted to ONE kernel per frame on one stream
-    # (RT_TWO_STREAMS=0): HIP events around those K launches give the kernel's average launch
-    # duration, the figure rocprofv3 --kernel-trace reports for the same mode (profiles/).
+    # (RT_TWO_STREAMS=0): HIP events around those K launches give the kernel's average launch duration,
+    # the figure rocprofv3 --kernel-trace reports for the same mode (profiles/).
     single_ms = None
     if rank == 0:
         if os.environ.get("RT_TWO_STREAMS") == "0":
             single_ms = timed["gpuMs"] / args.steps
         else:
-            os.environ["RT_TWO_STREAMS"] = "0"
-            t1s = api.create_tracer(dev_index)
-            del os.environ["RT_TWO_STREAMS"]
-            if tiled:
-                t1s.set_partition(pkg.dist.STRIP_ROWS, rank, world)
-            m1 = scene.make_manager(t1s, api, W, H)
-            m1.OnEnable(renderSeed=1)
-            for _ in range(args.warmup):
-                m1.RenderFrame()
-            t1s.synchronize()
-            t1s.reset_counters()
-            t1s.timer_begin()
-            for _ in range(args.steps):
-                t1s.render_frame()
-            t1s.timer_end()
-            one = t1s.counters()
-            assert one["segments"] == segments, (one["segments"], segments)
-            single_ms = one["gpuMs"] / args.steps
-            t1s.close()
+            single_ms, seg1 = single_launch_ms(pkg, api, dev_index, args.config, W, H, args.steps, args.warmup,
+                                               (pkg.dist.STRIP_ROWS, rank, world) if tiled else None)
+            assert seg1 == segments, (seg1, segments)
 
     # ---- readback: the one collective of the multi-GPU path
     gather_ms = None
@@ -212,9 +418,9 @@ def main():
         del full
 
     if world > 1:
-        t = torch.tensor([elapsed, float(timed["gpuMs"])], dtype=torch.float64, device=comm_device)
+        t = torch.tensor([elapsed, float(timed["gpuMs"]), init_elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms_max = t[0].item(), t[1].item()
+        elapsed, kernel_ms_max, init_elapsed = t[0].item(), t[1].item(), t[2].item()
         s = torch.tensor([segments, pkg.abi.algorithmic_bytes(stats, n_models, n_spheres)], dtype=torch.float64, device=comm_device)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         total_segments, total_bytes = s[0].item(), s[1].item()
@@ -224,20 +430,27 @@ def main():
         total_bytes = float(pkg.abi.algorithmic_bytes(stats, n_models, n_spheres))
 
     if rank == 0:
-        # roofline of the dominant (only) kernel, rt_trace_kernel: algorithmic bytes of THIS
-        # rank's launch / its average duration from HIP events on the launch stream
         my_bytes = pkg.abi.algorithmic_bytes(stats, n_models, n_spheres) / args.steps
-        my_ms = single_ms
-        achieved = my_bytes / (my_ms * 1e-3) / 1e9
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(prof):
-            with open(prof) as f:
-                pj = json.load(f)
-            key = f"config{args.config}_n{world}"
-            traffic = pj.get(key, {}).get("hbm_bytes_per_launch")
+        spp, mb = scene.settings["numRaysPerPixel"], scene.settings["maxBounceCount"]
+        # ---- VALU roofline of the dominant (only) kernel
+        pmc = None
+        if world == 1 and not args.no_pmc:
+            pmc = collect_pmc(args.config, min(args.steps, 6), 1, with_traffic=True)
+        if pmc is None:
+            pmc = replayed_pmc(args.config)
+        roof = None
+        if pmc is not None:
+            roof = valu_roofline(pmc, single_ms, segments / args.steps)
+            roof["kernel"] = ("rt_trace_kernel<false, *>: whole-frame launches (one kernel per frame, RT_TWO_STREAMS=0 pass); the "
+                              "half-frame launches of the timed pass run the same code as rt_trace_half_kernel")
+            roof["peak_derivation"] = "256 CU x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)"
+            roof["secondary_hbm_algorithmic"] = {
+                "what": "SURVEY.md 8(d) algorithmic bytes (the reference loop's loads for the counted work) / launch time; the scene is "
+                        "SGPR/L2 resident, so this is NOT a roof and may exceed 8 TB/s — kept for continuity with round 1",
+                "bytes_per_launch": my_bytes, "GBps": my_bytes / (single_ms * 1e-3) / 1e9}
+        parity = parity_check(pkg, api, dev_index, args.config, W, H, (3, H // 16, H // 8 - 2)) if world == 1 else None
         out = {
-            "metric": "Mrays/s at 1920x1080, 8 spp, 8 bounces; per-channel L2 vs reference",
+            "metric": f"Mrays/s at {W}x{H}, {spp} spp, {mb} bounces; per-channel L2 vs reference",
             "value": total_segments / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -248,8 +461,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{scene.name}: {W}x{H}, {scene.settings['numRaysPerPixel']} spp/frame, "
-                            f"{scene.settings['maxBounceCount']} bounces, {n_spheres} spheres + {n_models} models "
+                "workload": f"{scene.name}: {W}x{H}, {spp} spp/frame, {mb} bounces, {n_spheres} spheres + {n_models} models "
                             f"({scene.unique_triangles()} triangles); "
                             + (f"BASELINE.json configs[{args.config - 1}]" if args.config <= 5 else "the reference's own scene file, not a BASELINE config"),
                 "parallelism": "single GPU" if world == 1 else f"{W}x{H} image row-tiled, cyclic 8-row strips over {world} GPUs "
@@ -257,25 +469,32 @@ def main():
                 "renderSeed": 1, "first_timed_frame": first_frame,
             },
             "segments_per_step": total_segments / args.steps,
-            "mpaths_per_s": W * H * scene.settings["numRaysPerPixel"] * args.steps / elapsed / 1e6,
+            "mpaths_per_s": W * H * spp * args.steps / elapsed / 1e6,
             "resolution": [W, H],
             "kernel_ms_per_step": kernel_ms_max / args.steps,
+            "value_with_initframe": total_segments / init_elapsed / 1e6,
+            "ms_per_step_with_initframe": init_elapsed / args.steps * 1e3,
             "gather_ms": gather_ms,
             "launches": "2 kernels per frame on 2 streams (disjoint tile halves, overlapping in time)"
                         if os.environ.get("RT_TWO_STREAMS") != "0" else "1 kernel per frame",
             "batched_api": batched,
-            "parity": "bit-identical to oracle/ on tests/ (pytest -m gpu); max rel err 0",
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "rt_trace_kernel<false, *> (whole-frame launches of the roofline pass; the two half-frame "
-                          "launches per step of the timed pass run the same code as rt_trace_half_kernel)",
-                "algorithmic_bytes_per_launch": my_bytes, "avg_launch_ms": my_ms,
-                "note": "algorithmic bytes = the reference loop's loads for the counted work (SURVEY.md 8(d)); "
-                        "the scene is cache/SGPR resident, so frac can exceed what HBM itself delivers. "
-                        "avg_launch_ms: one kernel per frame on one stream (RT_TWO_STREAMS=0 pass), HIP events",
-            },
+            "parity": parity if parity is not None else "checked at N=1 (pytest -m gpu and the N=1 bench line)",
+            "roofline": roof,
         }
+        # ---- the same roofline for BVH workloads (north_star's roofline clause is about BVH traversal, RC:234-287)
+        if world == 1 and args.config == 2 and not args.no_secondary:
+            sec = {}
+            for cfg in (3, 4):
+                sc2 = pkg.scenes.get(cfg)
+                ms2, seg2 = single_launch_ms(pkg, api, dev_index, cfg, sc2.width, sc2.height, 6, 1)
+                p2 = (None if args.no_pmc else collect_pmc(cfg, 4, 1, with_traffic=False)) or replayed_pmc(cfg)
+                if p2 is None:
+                    continue
+                r2 = valu_roofline(p2, ms2, seg2 / 6)
+                r2["mrays_per_s_one_kernel_per_frame"] = seg2 / 6 / (ms2 * 1e-3) / 1e6
+                r2["workload"] = f"{sc2.name}: {sc2.width}x{sc2.height}, {sc2.unique_triangles()} triangles, BASELINE.json configs[{cfg - 1}]"
+                sec[f"config{cfg}"] = r2
+            out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, args.config, W, H)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

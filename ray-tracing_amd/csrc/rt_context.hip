@@ -94,6 +94,12 @@ struct RtContext {
     int gridOverride = 0; /* test hook: force the persistent grid size */
     bool stats = false;
     uint64_t pixelFrames = 0;
+    /* pinned staging ring of the per-frame update calls (rt_update_models / rt_update_spheres): the
+     * uploads are enqueued on the render stream, no host synchronisation */
+    struct Staging { void* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool inFlight = false; };
+    Staging staging[8];
+    int stagingNext = 0;
+    uint64_t updateUploads = 0, updateSkips = 0; /* diagnostics: uploads enqueued / calls that changed nothing */
     hipEvent_t evStart = nullptr, evStop = nullptr;
     double gpuMs = 0;
     int timerState = 0; /* 0 idle, 1 begun, 2 ended (elapsed not yet read) */
@@ -151,6 +157,37 @@ static void flush_timer(RtContext* ctx)
         if (hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop) == hipSuccess) ctx->gpuMs += ms;
         ctx->timerState = 0;
     }
+}
+
+/* Stream-ordered host->device upload: the bytes are copied into a pinned staging slot now and the
+ * transfer is enqueued on the (joined) render stream, i.e. after every frame already enqueued and
+ * before the next one; the caller's memory is free on return and the host never waits for the GPU
+ * (only when all 8 slots are still in flight, which a per-frame caller does not reach). */
+static int stage_upload(RtContext* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!bytes) return RT_OK;
+    RtContext::Staging& s = ctx->staging[ctx->stagingNext];
+    ctx->stagingNext = (ctx->stagingNext + 1) % 8;
+    if (s.inFlight) {
+        HIP_TRY(ctx, hipEventSynchronize(s.done));
+        s.inFlight = false;
+    }
+    if (s.cap < bytes) {
+        if (s.host) hipHostFree(s.host);
+        s.host = nullptr;
+        s.cap = 0;
+        size_t cap = bytes < 4096 ? 4096 : bytes + bytes / 2;
+        HIP_TRY(ctx, hipHostMalloc(&s.host, cap, hipHostMallocDefault));
+        s.cap = cap;
+    }
+    if (!s.done) HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    memcpy(s.host, src, bytes);
+    hipStream_t st = joined(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(dst, s.host, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipEventRecord(s.done, st));
+    s.inFlight = true;
+    ctx->updateUploads++;
+    return RT_OK;
 }
 
 extern "C" {
@@ -229,6 +266,10 @@ void rt_destroy(RtContext* ctx)
     hipFree(ctx->dTileQueue);
     hipFree(ctx->dTileCost);
     hipFree(ctx->dTileOrder);
+    for (RtContext::Staging& st : ctx->staging) {
+        if (st.host) hipHostFree(st.host);
+        if (st.done) hipEventDestroy(st.done);
+    }
     if (ctx->evStart) hipEventDestroy(ctx->evStart);
     if (ctx->evStop) hipEventDestroy(ctx->evStop);
     if (ctx->evFork) hipEventDestroy(ctx->evFork);
@@ -702,22 +743,32 @@ int rt_update_models(RtContext* ctx, const RtModel* models, int n_models)
     if (!ctx->haveScene) return fail(ctx, RT_ERR_STATE, "rt_update_models before rt_upload_scene");
     if (n_models != ctx->nModels || (n_models && !models)) return fail(ctx, RT_ERR_INVALID_ARG, "rt_update_models: model count changed (%d != %d)", n_models, ctx->nModels);
     if (n_models == 0) return RT_OK;
+    /* RCM:192-204 runs every frame; in a static scene nothing changed: no device work at all */
+    if (memcmp(models, ctx->hModels.data(), sizeof(RtModel) * (size_t)n_models) == 0) {
+        ctx->updateSkips++;
+        return RT_OK;
+    }
     std::vector<DModel> dmodels(n_models);
     std::vector<DMaterial> mats(n_models);
+    bool matricesChanged = false;
     for (int i = 0; i < n_models; i++) {
         if (models[i].nodeOffset != ctx->hModels[i].nodeOffset || models[i].triOffset != ctx->hModels[i].triOffset)
             return fail(ctx, RT_ERR_INVALID_ARG, "rt_update_models: model %d changed its BVH offsets; re-upload the scene", i);
         pack_model(models[i], ctx->hRootCodes[i], dmodels[i]);
         pack_material(models[i].material, mats[i]);
+        if (memcmp(models[i].worldToLocal, ctx->hModels[i].worldToLocal, sizeof(models[i].worldToLocal)) != 0 ||
+            memcmp(models[i].localToWorld, ctx->hModels[i].localToWorld, sizeof(models[i].localToWorld)) != 0)
+            matricesChanged = true;
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
-    HIP_TRY(ctx, hipMemcpy(ctx->dModels, dmodels.data(), sizeof(DModel) * n_models, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->dMaterials + ctx->nSpheres, mats.data(), sizeof(DMaterial) * n_models, hipMemcpyHostToDevice));
-    {
+    /* stream-ordered: lands after the frames already enqueued, before the next launch */
+    int rc;
+    if ((rc = stage_upload(ctx, ctx->dModels, dmodels.data(), sizeof(DModel) * n_models))) return rc;
+    if ((rc = stage_upload(ctx, ctx->dMaterials + ctx->nSpheres, mats.data(), sizeof(DMaterial) * n_models))) return rc;
+    if (matricesChanged) { /* the world-space root filter boxes depend on the matrices only */
         std::vector<DFilter> filters;
         make_filters(models, n_models, ctx->hRootCodes, ctx->hRootChildren, ctx->hSpheres.data(), (int)ctx->hSpheres.size(), filters, &ctx->filterMaxOrigin);
-        HIP_TRY(ctx, hipMemcpy(ctx->dFilters, filters.data(), sizeof(DFilter) * n_models, hipMemcpyHostToDevice));
+        if ((rc = stage_upload(ctx, ctx->dFilters, filters.data(), sizeof(DFilter) * n_models))) return rc;
     }
     ctx->hModels.assign(models, models + n_models);
     return RT_OK;
@@ -729,19 +780,23 @@ int rt_update_spheres(RtContext* ctx, const RtSphere* spheres, int n_spheres)
     if (!ctx->haveScene) return fail(ctx, RT_ERR_STATE, "rt_update_spheres before rt_upload_scene");
     if (n_spheres != ctx->nSpheres || (n_spheres && !spheres)) return fail(ctx, RT_ERR_INVALID_ARG, "rt_update_spheres: sphere count changed");
     if (n_spheres == 0) return RT_OK;
+    if (memcmp(spheres, ctx->hSpheres.data(), sizeof(RtSphere) * (size_t)n_spheres) == 0) {
+        ctx->updateSkips++;
+        return RT_OK;
+    }
     std::vector<float> sph;
     pack_spheres(spheres, n_spheres, sph, &ctx->sphereBound);
     std::vector<DMaterial> mats(n_spheres);
     for (int i = 0; i < n_spheres; i++) pack_material(spheres[i].material, mats[i]);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
-    HIP_TRY(ctx, hipMemcpy(ctx->dSpheres, sph.data(), sph.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->dMaterials, mats.data(), sizeof(DMaterial) * n_spheres, hipMemcpyHostToDevice));
+    int rc;
+    if ((rc = stage_upload(ctx, ctx->dSpheres, sph.data(), sph.size() * 4))) return rc;
+    if ((rc = stage_upload(ctx, ctx->dMaterials, mats.data(), sizeof(DMaterial) * n_spheres))) return rc;
     ctx->hSpheres.assign(spheres, spheres + n_spheres);
-    if (ctx->nModels) {
+    if (ctx->nModels) { /* the filter margins scale with the scene extent, which includes the spheres */
         std::vector<DFilter> filters;
         make_filters(ctx->hModels.data(), ctx->nModels, ctx->hRootCodes, ctx->hRootChildren, spheres, n_spheres, filters, &ctx->filterMaxOrigin);
-        HIP_TRY(ctx, hipMemcpy(ctx->dFilters, filters.data(), sizeof(DFilter) * ctx->nModels, hipMemcpyHostToDevice));
+        if ((rc = stage_upload(ctx, ctx->dFilters, filters.data(), sizeof(DFilter) * ctx->nModels))) return rc;
     }
     return RT_OK;
 }
