@@ -246,6 +246,38 @@ int rt_display_srgb8(RtContext* ctx, int frame, int use_accumulated, int flip_y,
  * counter and seed travel in RtParams).  local_rows*W*16 bytes. */
 int rt_write_accumulated(RtContext* ctx, const float* rgba, size_t bytes);
 
+/* ---- several GPUs from ONE host process (no reference counterpart) ------
+ * For hosts that are not one-process-per-GPU launchers (the C# / C++ console hosts): n contexts, one
+ * per entry of device_ids, context i owning the cyclic 8-row strips s % n == i of the image
+ * (rt_set_partition(ctx_i, 8, i, n)).  The scene is replicated, every call below is forwarded to all
+ * contexts (launches are asynchronous, so the devices run concurrently from one host thread), and the
+ * only exchange is the gather at readback: rt_gather_accumulated / rt_gather_frame copy every
+ * context's packed rows into their GLOBAL rows of a full H*W*16-byte host image (row 0 = bottom).
+ * A device id may appear more than once (virtual shards on one GPU — how the 1-GPU tests cover this).
+ * The image equals the single-context image bit for bit.  The one-process-per-GPU form of the same
+ * tiling is rt_set_partition + rt_bind_render_targets + an RCCL gather (ray_tracing_amd/dist.py). */
+typedef struct RtMulti RtMulti;
+int rt_create_multi(const int* device_ids, int n_devices, RtMulti** out);
+void rt_destroy_multi(RtMulti* m);
+int rt_multi_count(const RtMulti* m);
+/* The i-th context, for per-context calls (counters, timers, display, rt_last_error ...). */
+RtContext* rt_multi_context(RtMulti* m, int i);
+int rt_multi_resize(RtMulti* m, int width, int height);
+int rt_multi_upload_scene(RtMulti* m, const RtModel* models, int n_models, const RtTriangle* triangles, int n_triangles,
+                          const RtBVHNode* nodes, int n_nodes, const RtSphere* spheres, int n_spheres);
+int rt_multi_update_models(RtMulti* m, const RtModel* models, int n_models);
+int rt_multi_update_spheres(RtMulti* m, const RtSphere* spheres, int n_spheres);
+int rt_multi_set_params(RtMulti* m, const RtParams* params);
+int rt_multi_reset_accumulation(RtMulti* m);
+int rt_multi_render_frame(RtMulti* m);
+int rt_multi_render_frames(RtMulti* m, int n);
+int rt_multi_synchronize(RtMulti* m);
+/* bytes must be H*W*16.  Synchronises every context. */
+int rt_gather_accumulated(RtMulti* m, float* rgba, size_t bytes);
+int rt_gather_frame(RtMulti* m, float* rgba, size_t bytes);
+/* Sum of the contexts' counters (gpuMs: the maximum). */
+int rt_multi_get_counters(RtMulti* m, RtCounters* out);
+
 /* ---- device timing ---------------------------------------------------------- */
 /* HIP events recorded on the stream the kernels are launched on: the device
  * time between rt_timer_begin and rt_timer_end is added to RtCounters.gpuMs

@@ -1245,4 +1245,111 @@ int rt_debug_math_eval(RtContext* ctx, int op, const float* x, const float* y, f
     return RT_OK;
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * Several GPUs from one host process: n contexts with cyclic 8-row strips, gather at readback.
+ * ---------------------------------------------------------------------------------------- */
+struct RtMulti {
+    std::vector<RtContext*> ctx;
+    std::vector<float> tile; /* staging of one context's packed rows */
+};
+
+int rt_create_multi(const int* device_ids, int n_devices, RtMulti** out)
+{
+    if (!out) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create_multi: out is null");
+    *out = nullptr;
+    if (!device_ids || n_devices <= 0) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create_multi: no devices");
+    RtMulti* m = new RtMulti();
+    for (int i = 0; i < n_devices; i++) {
+        RtContext* c = nullptr;
+        int rc = rt_create(device_ids[i], &c);
+        if (rc == RT_OK) rc = rt_set_partition(c, 8, i, n_devices);
+        if (rc != RT_OK) {
+            if (c) rt_destroy(c);
+            rt_destroy_multi(m);
+            return rc;
+        }
+        m->ctx.push_back(c);
+    }
+    *out = m;
+    return RT_OK;
+}
+
+void rt_destroy_multi(RtMulti* m)
+{
+    if (!m) return;
+    for (RtContext* c : m->ctx) rt_destroy(c);
+    delete m;
+}
+
+int rt_multi_count(const RtMulti* m) { return m ? (int)m->ctx.size() : 0; }
+RtContext* rt_multi_context(RtMulti* m, int i) { return (m && i >= 0 && i < (int)m->ctx.size()) ? m->ctx[i] : nullptr; }
+
+#define RT_MULTI_FORWARD(call)                                                 \
+    do {                                                                       \
+        if (!m) return fail(nullptr, RT_ERR_INVALID_ARG, "null multi context"); \
+        for (RtContext* c : m->ctx) {                                          \
+            int rc_ = (call);                                                  \
+            if (rc_ != RT_OK) return rc_;                                      \
+        }                                                                      \
+        return RT_OK;                                                          \
+    } while (0)
+
+int rt_multi_resize(RtMulti* m, int width, int height) { RT_MULTI_FORWARD(rt_resize(c, width, height)); }
+int rt_multi_upload_scene(RtMulti* m, const RtModel* models, int n_models, const RtTriangle* triangles, int n_triangles,
+                          const RtBVHNode* nodes, int n_nodes, const RtSphere* spheres, int n_spheres)
+{
+    RT_MULTI_FORWARD(rt_upload_scene(c, models, n_models, triangles, n_triangles, nodes, n_nodes, spheres, n_spheres));
+}
+int rt_multi_update_models(RtMulti* m, const RtModel* models, int n_models) { RT_MULTI_FORWARD(rt_update_models(c, models, n_models)); }
+int rt_multi_update_spheres(RtMulti* m, const RtSphere* spheres, int n_spheres) { RT_MULTI_FORWARD(rt_update_spheres(c, spheres, n_spheres)); }
+int rt_multi_set_params(RtMulti* m, const RtParams* params) { RT_MULTI_FORWARD(rt_set_params(c, params)); }
+int rt_multi_reset_accumulation(RtMulti* m) { RT_MULTI_FORWARD(rt_reset_accumulation(c)); }
+int rt_multi_render_frame(RtMulti* m) { RT_MULTI_FORWARD(rt_render_frame(c)); }
+int rt_multi_render_frames(RtMulti* m, int n) { RT_MULTI_FORWARD(rt_render_frames(c, n)); }
+int rt_multi_synchronize(RtMulti* m) { RT_MULTI_FORWARD(rt_synchronize(c)); }
+
+static int multi_gather(RtMulti* m, float* rgba, size_t bytes, bool accumulated)
+{
+    if (!m || m->ctx.empty()) return fail(nullptr, RT_ERR_INVALID_ARG, "null multi context");
+    RtContext* c0 = m->ctx[0];
+    const int W = c0->W, H = c0->H;
+    if (!rgba || bytes != (size_t)W * H * 16) return fail(c0, RT_ERR_INVALID_ARG, "rt_gather: bytes %zu != H*W*16 = %zu", bytes, (size_t)W * H * 16);
+    for (RtContext* c : m->ctx) {
+        if (c->W != W || c->H != H) return fail(c0, RT_ERR_STATE, "rt_gather: contexts disagree on the resolution");
+        const int rows = c->localRows;
+        if (!rows) continue;
+        const size_t rowBytes = (size_t)W * 16;
+        m->tile.resize((size_t)rows * W * 4);
+        int rc = accumulated ? rt_read_accumulated(c, m->tile.data(), (size_t)rows * rowBytes) : rt_read_frame(c, m->tile.data(), (size_t)rows * rowBytes);
+        if (rc != RT_OK) return rc;
+        /* packed local rows -> their global rows; a strip's rows are contiguous in both */
+        for (int l = 0; l < rows;) {
+            const int g = rt_local_to_global_row(c, l);
+            int run = c->stripRows - (g % c->stripRows);
+            if (run > rows - l) run = rows - l;
+            memcpy((char*)rgba + (size_t)g * rowBytes, (const char*)m->tile.data() + (size_t)l * rowBytes, (size_t)run * rowBytes);
+            l += run;
+        }
+    }
+    return RT_OK;
+}
+int rt_gather_accumulated(RtMulti* m, float* rgba, size_t bytes) { return multi_gather(m, rgba, bytes, true); }
+int rt_gather_frame(RtMulti* m, float* rgba, size_t bytes) { return multi_gather(m, rgba, bytes, false); }
+
+int rt_multi_get_counters(RtMulti* m, RtCounters* out)
+{
+    if (!m || !out) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_multi_get_counters: null argument");
+    memset(out, 0, sizeof(*out));
+    for (RtContext* c : m->ctx) {
+        RtCounters k;
+        int rc = rt_get_counters(c, &k);
+        if (rc != RT_OK) return rc;
+        out->segments += k.segments; out->innerSteps += k.innerSteps; out->leafSteps += k.leafSteps; out->triTests += k.triTests;
+        out->sphereTests += k.sphereTests; out->modelVisits += k.modelVisits; out->pixelFrames += k.pixelFrames;
+        if (k.gpuMs > out->gpuMs) out->gpuMs = k.gpuMs;
+    }
+    return RT_OK;
+}
+
 } /* extern "C" */

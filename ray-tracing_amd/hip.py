@@ -22,6 +22,10 @@ ABI_SYMBOLS = [
     "rt_write_accumulated", "rt_timer_begin", "rt_timer_end",
     "rt_enable_stats", "rt_reset_counters", "rt_get_counters", "rt_build_bvh", "rt_build_bvh_mt", "rt_camera_view_params", "rt_version",
     "rt_debug_intersect", "rt_debug_math_eval", "rt_debug_phase_profile",
+    "rt_create_multi", "rt_destroy_multi", "rt_multi_count", "rt_multi_context", "rt_multi_resize", "rt_multi_upload_scene",
+    "rt_multi_update_models", "rt_multi_update_spheres", "rt_multi_set_params", "rt_multi_reset_accumulation",
+    "rt_multi_render_frame", "rt_multi_render_frames", "rt_multi_synchronize", "rt_gather_accumulated", "rt_gather_frame",
+    "rt_multi_get_counters",
 ]
 
 
@@ -43,6 +47,22 @@ class HipApi(abi.CApi):
         "debug_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
         "debug_math_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
         "debug_phase_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+        "create_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+        "destroy_multi": (None, [C.c_void_p]),
+        "multi_count": (C.c_int, [C.c_void_p]),
+        "multi_context": (C.c_void_p, [C.c_void_p, C.c_int]),
+        "multi_resize": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+        "multi_upload_scene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+        "multi_update_models": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+        "multi_update_spheres": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+        "multi_set_params": (C.c_int, [C.c_void_p, C.POINTER(abi.RtParams)]),
+        "multi_reset_accumulation": (C.c_int, [C.c_void_p]),
+        "multi_render_frame": (C.c_int, [C.c_void_p]),
+        "multi_render_frames": (C.c_int, [C.c_void_p, C.c_int]),
+        "multi_synchronize": (C.c_int, [C.c_void_p]),
+        "gather_accumulated": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+        "gather_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+        "multi_get_counters": (C.c_int, [C.c_void_p, C.POINTER(abi.RtCounters)]),
     }
 
     def __init__(self, path=LIB_PATH):
@@ -77,6 +97,97 @@ class HipApi(abi.CApi):
             msg = self.last_error(None)
             raise abi.RtError(rc, msg.decode() if msg else "rt_create failed")
         return HipTracer(self, h.value)
+
+    def create_multi_tracer(self, device_ids):
+        return MultiTracer(self, list(device_ids))
+
+
+class MultiTracer:
+    """rt_create_multi: n contexts (one per device id) in THIS process, cyclic 8-row strips, gather at
+    readback.  Quacks like a Tracer for the RayComputeManager mirror (resize / upload_scene / update_models /
+    set_params / reset_accumulation / render_frame(s) / read_accumulated)."""
+
+    def __init__(self, api, device_ids):
+        self.api = api
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        rc = api.create_multi(ids, len(device_ids), C.byref(h))
+        if rc != abi.RT_OK:
+            msg = api.last_error(None)
+            raise abi.RtError(rc, msg.decode() if msg else "rt_create_multi failed")
+        self.h = h.value
+        self.size = (0, 0)
+
+    def _check(self, rc):
+        if rc != abi.RT_OK:
+            msg = self.api.last_error(self.api.multi_context(self.h, 0))
+            raise abi.RtError(rc, msg.decode() if msg else "")
+
+    def close(self):
+        if self.h:
+            self.api.destroy_multi(self.h)
+            self.h = None
+
+    def context(self, i):
+        """Borrowed per-device context (owned by the multi handle: closing it is a no-op)."""
+        t = _BorrowedTracer(self.api, self.api.multi_context(self.h, i))
+        t.width, t.height = self.size
+        return t
+
+    def resize(self, w, h):
+        self._check(self.api.multi_resize(self.h, w, h))
+        self.size = (w, h)
+
+    def upload_scene(self, models, triangles, nodes, spheres=None):
+        m, nm = abi._ptr(models, abi.model_dtype)
+        t, nt = abi._ptr(triangles, abi.triangle_dtype)
+        n, nn = abi._ptr(nodes, abi.node_dtype)
+        sp, ns = abi._ptr(spheres, abi.sphere_dtype)
+        self._check(self.api.multi_upload_scene(
+            self.h, m.ctypes.data if nm else None, nm, t.ctypes.data if nt else None, nt,
+            n.ctypes.data if nn else None, nn, sp.ctypes.data if ns else None, ns))
+
+    def update_models(self, models):
+        m, nm = abi._ptr(models, abi.model_dtype)
+        self._check(self.api.multi_update_models(self.h, m.ctypes.data if nm else None, nm))
+
+    def update_spheres(self, spheres):
+        sp, ns = abi._ptr(spheres, abi.sphere_dtype)
+        self._check(self.api.multi_update_spheres(self.h, sp.ctypes.data if ns else None, ns))
+
+    def set_params(self, params):
+        params.abi_version = abi.RT_ABI_VERSION
+        params.struct_size = C.sizeof(abi.RtParams)
+        self._check(self.api.multi_set_params(self.h, C.byref(params)))
+
+    def reset_accumulation(self):
+        self._check(self.api.multi_reset_accumulation(self.h))
+
+    def render_frame(self):
+        self._check(self.api.multi_render_frame(self.h))
+
+    def render_frames(self, n):
+        self._check(self.api.multi_render_frames(self.h, n))
+
+    def synchronize(self):
+        self._check(self.api.multi_synchronize(self.h))
+
+    def _gather(self, fn):
+        w, h = self.size
+        out = np.zeros((h, w, 4), dtype=np.float32)
+        self._check(fn(self.h, out.ctypes.data, out.nbytes))
+        return out
+
+    def read_accumulated(self):
+        return self._gather(self.api.gather_accumulated)
+
+    def read_frame(self):
+        return self._gather(self.api.gather_frame)
+
+    def counters(self):
+        c = abi.RtCounters()
+        self._check(self.api.multi_get_counters(self.h, C.byref(c)))
+        return c.as_dict()
 
 
 class HipTracer(abi.Tracer):
@@ -137,6 +248,11 @@ class HipTracer(abi.Tracer):
         out = np.empty_like(x)
         self._check(self.api.debug_math_eval(self.h, int(op), x.ctypes.data, y.ctypes.data, out.ctypes.data, len(x)))
         return out
+
+
+class _BorrowedTracer(HipTracer):
+    def close(self):
+        self.h = None
 
 
 _api = None

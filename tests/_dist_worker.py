@@ -13,7 +13,47 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 
+def main_gpu():
+    """The real library on one device: every rank = a context restricted by rt_set_partition, rendering into
+    torch tensors bound with rt_bind_render_targets, tiles gathered by ray_tracing_amd.dist (gloo here because
+    RCCL refuses two ranks on one GPU) — the exact code path of `bench.py --gpus N`, checked against the oracle."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    W, H, frames, cfg = 104, 77, 3, int(sys.argv[2])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = graft.load_package()
+    api = pkg.load_library()
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    tracer = api.create_tracer(0)
+    tiled = pkg.dist.TiledTracer(tracer, rank, world, device)
+    mgr = pkg.scenes.get(cfg).make_manager(tracer, api, W, H)
+    mgr.OnEnable(renderSeed=3)
+    tiled.bind(W, H)
+    tracer.reset_accumulation()
+    for _ in range(frames):
+        mgr.RenderFrame()
+    img = tiled.gather_accumulated(H, comm_device=torch.device("cpu"))
+    segs = torch.tensor([tracer.counters()["segments"]], dtype=torch.float64)
+    dist.all_reduce(segs)
+    if rank == 0:
+        orc = graft.load_oracle()
+        ref = orc.create_tracer(4)
+        m2 = pkg.scenes.get(cfg).make_manager(ref, orc, W, H)
+        m2.OnEnable(renderSeed=3)
+        m2.RenderFrames(frames)
+        want = ref.read_accumulated()
+        got = img.numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "tiled GPU render != oracle"
+        assert int(segs.item()) == ref.counters()["segments"]
+        print("DIST_GPU_OK", world, int(segs.item()))
+    tracer.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
+    if sys.argv[1] == "gpu":
+        return main_gpu()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     W, H, frames, cfg = 40, 45, 2, int(sys.argv[1])
     dist.init_process_group("gloo", rank=rank, world_size=world)

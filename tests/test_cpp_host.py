@@ -75,3 +75,27 @@ def test_cpp_host_render_equals_oracle(pkg, orc, bench, tmp_path, cfg):
     assert tr.counters()["segments"] == info["segments"]
     tr.close()
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_cpp_host_several_devices_from_one_process(pkg, orc, bench, tmp_path, devices):
+    """rt_create_multi through the compiled host: one context per listed device (the same GPU several times
+    = virtual shards), cyclic 8-row strips, rt_gather_accumulated -> the oracle's image, bit for bit."""
+    prefix = str(tmp_path / "m3")
+    out = subprocess.check_output([bench, "--config", "3", "--width", "96", "--height", "70", "--frames", "3", "--devices", devices,
+                                   "--dump", prefix], text=True)
+    info = json.loads(out.strip().splitlines()[-1])
+    assert info["devices"] == len(devices.split(",")) and info["segments"] > 0
+    models, tris, nodes, spheres, params = _load(pkg, prefix)
+    got = np.fromfile(prefix + ".accumulated.bin", dtype=np.float32).reshape(70, 96, 4)
+    tr = orc.create_tracer(8)
+    tr.resize(96, 70)
+    tr.upload_scene(models, tris, nodes, spheres)
+    tr.set_params(params)
+    tr.reset_accumulation()
+    tr.render_frames(3)
+    want = tr.read_accumulated()
+    assert tr.counters()["segments"] == info["segments"]
+    tr.close()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

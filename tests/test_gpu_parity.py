@@ -323,6 +323,24 @@ def test_config5_full_size_strip_sample(pkg, api, orc):
     _strips_against_oracle(pkg, api, orc, 5, (101, 150))
 
 
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_multi_device_entry_equals_single_context(pkg, api, n):
+    """rt_create_multi with the same device n times (virtual shards): the manager mirror drives it like a
+    tracer; the gathered image and the summed counters equal the single-context render."""
+    single = api.create_tracer(0)
+    a, _ = render(pkg, api, single, 3, 120, 100, 3)
+    ca = single.counters()
+    single.close()
+    multi = api.create_multi_tracer([0] * n)
+    b, _ = render(pkg, api, multi, 3, 120, 100, 3)
+    cb = multi.counters()
+    rows = [multi.context(i).local_rows() for i in range(n)]
+    multi.close()
+    assert sum(rows) == 100 and max(rows) - min(rows) <= 8
+    assert bits_equal(a, b)
+    assert ca["segments"] == cb["segments"] and cb["pixelFrames"] == 3 * 120 * 100
+
+
 # ------------------------------------------------------------------ scheduling must not change results
 @pytest.mark.parametrize("grid", ["1", "3", "1000000"])
 def test_persistent_grid_size_does_not_change_results(pkg, api, orc, grid, monkeypatch):
