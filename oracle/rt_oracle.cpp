@@ -54,7 +54,8 @@ struct Counters {
 
 /* Optional per-thread log of the work one pixel does, as a byte stream (tools/sched_sim2.py models
  * the kernel's scheduling on it; not a reference feature):
- *   'R' camera ray | 'S' segment start | 'A' model entered | 'B' inner step | 'C' n = leaf with n tests |
+ *   'R' camera ray | 'S' segment start | 'A' model entered | 'B' d = inner step | 'C' n d = leaf with n tests
+ *   (d = entries left on the traversal stack when the node is popped) |
  *   'K' miss (sky) | 'O' opaque hit | 'G' glass hit | 'E' path ended */
 static thread_local std::vector<uint8_t>* g_schedTrace = nullptr;
 static inline void sched_tok(uint8_t t) { if (g_schedTrace) g_schedTrace->push_back(t); }
@@ -195,7 +196,7 @@ static TriangleHitInfo RayTriangleBVH(const Scene& sc, const Ray& ray, float ray
 
         if (isLeaf) {
             stats.leafSteps++;
-            sched_tok('C'); sched_tok((uint8_t)(node.triangleCount > 255 ? 255 : node.triangleCount));
+            sched_tok('C'); sched_tok((uint8_t)(node.triangleCount > 255 ? 255 : node.triangleCount)); sched_tok((uint8_t)stackCount);
             for (int i = 0; i < node.triangleCount; i++) {
                 const RtTriangle& tri = sc.triangles[triOffset + node.startIndex + i];
                 TriangleHitInfo triHitInfo = RayTriangle(ray, tri, cullBackface);
@@ -207,7 +208,7 @@ static TriangleHitInfo RayTriangleBVH(const Scene& sc, const Ray& ray, float ray
             }
         } else {
             stats.innerSteps++;
-            sched_tok('B');
+            sched_tok('B'); sched_tok((uint8_t)stackCount);
             int childIndexA = nodeOffset + node.startIndex + 0;
             int childIndexB = nodeOffset + node.startIndex + 1;
             const RtBVHNode& childA = sc.nodes[childIndexA];

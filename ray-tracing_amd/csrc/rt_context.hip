@@ -59,6 +59,8 @@ struct RtContext {
     DTriN* dNorms = nullptr;
     uint32_t* dBigLeaves = nullptr;
     DFilter* dFilters = nullptr;
+    DChunk* dChunks = nullptr;  /* two-level model hierarchy, scenes with more than 64 models */
+    int nChunks = 0, nFiltered = 0, extWords = 0;
     float filterMaxOrigin = 0.0f;
     std::vector<RtBVHNode> hRootChildren;
     std::vector<RtSphere> hSpheres; /* per model: the root's two children (for rt_update_models) */
@@ -87,8 +89,8 @@ struct RtContext {
     long long nextSortAt = 1;
     bool lptEnabled = true;
     int numCUs = 256;
-    int occPerCU[4] = {0, 0, 0, 0};
-    size_t occBytes[4] = {0, 0, 0, 0};
+    int occPerCU[6] = {0, 0, 0, 0, 0, 0};
+    size_t occBytes[6] = {0, 0, 0, 0, 0, 0};
     bool verbose = false;
     bool fuseFrames = true; /* rt_render_frames(n): up to RT_MAX_FUSED_FRAMES frames per launch (RT_FUSE_FRAMES=0: one launch per frame) */
     int gridOverride = 0; /* test hook: force the persistent grid size */
@@ -250,6 +252,8 @@ static void free_scene(RtContext* ctx)
     hipFree(ctx->dNorms); ctx->dNorms = nullptr;
     hipFree(ctx->dBigLeaves); ctx->dBigLeaves = nullptr;
     hipFree(ctx->dFilters); ctx->dFilters = nullptr;
+    hipFree(ctx->dChunks); ctx->dChunks = nullptr;
+    ctx->nChunks = 0;
     ctx->haveScene = false;
 }
 
@@ -516,6 +520,75 @@ static void make_filters(const RtModel* models, int n_models, const std::vector<
     *maxOrigin = (float)(8.0 * extent);
 }
 
+/* Chunks of the two-level model hierarchy (rt_device.h, DChunk): only built for more than 64 models.
+ * Models the filter cannot reject (`always`) are kept in chunks of their own so that they do not spoil the
+ * boxes of the others; the rest is clustered by the Morton code of the filter box centre. */
+#define RT_MAX_FILTER_EXT_WORDS 32
+static void make_chunks(const std::vector<DFilter>& filters, std::vector<DChunk>& chunks, int* nFiltered, int* extWords)
+{
+    const int n = (int)filters.size();
+    chunks.clear();
+    *nFiltered = n < 64 ? n : 64;
+    *extWords = 0;
+    if (n <= 64) return;
+    const int maxModels = 63 + 32 * RT_MAX_FILTER_EXT_WORDS;
+    const int nf = n < maxModels ? n : maxModels;
+    *nFiltered = nf;
+    *extWords = (nf - 63 + 31) / 32;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < nf; i++)
+        if (!filters[i].always)
+            for (int d = 0; d < 3; d++) {
+                lo[d] = fmin(lo[d], (double)filters[i].bMin[d]);
+                hi[d] = fmax(hi[d], (double)filters[i].bMax[d]);
+            }
+    auto spread = [](uint32_t v) { /* 10 bits -> every third bit */
+        v &= 1023u;
+        v = (v | (v << 16)) & 0x030000ffu;
+        v = (v | (v << 8)) & 0x0300f00fu;
+        v = (v | (v << 4)) & 0x030c30c3u;
+        v = (v | (v << 2)) & 0x09249249u;
+        return v;
+    };
+    std::vector<std::pair<uint64_t, int>> order;
+    for (int i = 0; i < nf; i++) {
+        uint64_t key;
+        if (filters[i].always) {
+            key = (uint64_t)i; /* first, in index order */
+        } else {
+            uint32_t q[3];
+            for (int d = 0; d < 3; d++) {
+                const double c = 0.5 * ((double)filters[i].bMin[d] + (double)filters[i].bMax[d]);
+                const double t = hi[d] > lo[d] ? (c - lo[d]) / (hi[d] - lo[d]) : 0.0;
+                q[d] = (uint32_t)(t < 0 ? 0 : t > 1 ? 1023 : t * 1023.0);
+            }
+            key = (1ull << 40) | ((uint64_t)(spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2)) << 8);
+        }
+        order.push_back({key, i});
+    }
+    std::stable_sort(order.begin(), order.end(), [](const std::pair<uint64_t, int>& a, const std::pair<uint64_t, int>& b) { return a.first < b.first; });
+    for (size_t p = 0; p < order.size();) {
+        DChunk c;
+        memset(&c, 0, sizeof(c));
+        const bool alw = filters[order[p].second].always != 0;
+        c.always = alw ? 1u : 0u;
+        for (int d = 0; d < 3; d++) { c.bMin[d] = INFINITY; c.bMax[d] = -INFINITY; }
+        while (p < order.size() && c.count < RT_CHUNK_MODELS && (filters[order[p].second].always != 0) == alw) {
+            const DFilter& f = filters[order[p].second];
+            c.members[c.count++] = (uint32_t)order[p].second;
+            c.innerRoots += f.innerRoot;
+            if (!alw)
+                for (int d = 0; d < 3; d++) {
+                    c.bMin[d] = fminf(c.bMin[d], f.bMin[d]);
+                    c.bMax[d] = fmaxf(c.bMax[d], f.bMax[d]);
+                }
+            p++;
+        }
+        std::sort(c.members, c.members + c.count);
+        chunks.push_back(c);
+    }
+}
+
 struct SceneBuilder {
     const RtBVHNode* nodes;
     int nNodes, nTris;
@@ -635,6 +708,25 @@ static int upload_vec(RtContext* ctx, T** dptr, const void* src, size_t count)
     return RT_OK;
 }
 
+/* the filter boxes moved: the chunk boxes (and the spatial clustering) follow, stream-ordered */
+static int refresh_chunks(RtContext* ctx, const std::vector<DFilter>& filters)
+{
+    if (!ctx->nChunks) return RT_OK;
+    std::vector<DChunk> chunks;
+    int nf = 0, ew = 0;
+    make_chunks(filters, chunks, &nf, &ew);
+    if ((int)chunks.size() != ctx->nChunks) { /* a model became (un)filterable: the split into chunks changed size — rare, synchronous */
+        HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
+        hipFree(ctx->dChunks);
+        ctx->dChunks = nullptr;
+        int rc = upload_vec(ctx, &ctx->dChunks, chunks.data(), chunks.size());
+        if (rc) return rc;
+        ctx->nChunks = (int)chunks.size();
+        return RT_OK;
+    }
+    return stage_upload(ctx, ctx->dChunks, chunks.data(), sizeof(DChunk) * chunks.size());
+}
+
 extern "C" {
 
 int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const RtTriangle* triangles, int n_triangles,
@@ -719,6 +811,12 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
     if ((rc = upload_vec(ctx, &ctx->dNorms, dnorms.data(), dnorms.size()))) return rc;
     if ((rc = upload_vec(ctx, &ctx->dBigLeaves, sb.bigLeaves.data(), sb.bigLeaves.size()))) return rc;
     if ((rc = upload_vec(ctx, &ctx->dFilters, filters.data(), filters.size()))) return rc;
+    {
+        std::vector<DChunk> chunks;
+        make_chunks(filters, chunks, &ctx->nFiltered, &ctx->extWords);
+        if ((rc = upload_vec(ctx, &ctx->dChunks, chunks.data(), chunks.size()))) return rc;
+        ctx->nChunks = (int)chunks.size();
+    }
     ctx->filterMaxOrigin = maxOrigin;
     ctx->sphereBound = sphereBound;
     ctx->hRootChildren = rootChildren;
@@ -769,6 +867,7 @@ int rt_update_models(RtContext* ctx, const RtModel* models, int n_models)
         std::vector<DFilter> filters;
         make_filters(models, n_models, ctx->hRootCodes, ctx->hRootChildren, ctx->hSpheres.data(), (int)ctx->hSpheres.size(), filters, &ctx->filterMaxOrigin);
         if ((rc = stage_upload(ctx, ctx->dFilters, filters.data(), sizeof(DFilter) * n_models))) return rc;
+        if ((rc = refresh_chunks(ctx, filters))) return rc;
     }
     ctx->hModels.assign(models, models + n_models);
     return RT_OK;
@@ -797,6 +896,7 @@ int rt_update_spheres(RtContext* ctx, const RtSphere* spheres, int n_spheres)
         std::vector<DFilter> filters;
         make_filters(ctx->hModels.data(), ctx->nModels, ctx->hRootCodes, ctx->hRootChildren, spheres, n_spheres, filters, &ctx->filterMaxOrigin);
         if ((rc = stage_upload(ctx, ctx->dFilters, filters.data(), sizeof(DFilter) * ctx->nModels))) return rc;
+        if ((rc = refresh_chunks(ctx, filters))) return rc;
     }
     return RT_OK;
 }
@@ -844,6 +944,10 @@ static void fill_args(RtContext* ctx, int frame0, int nFrames, KArgs& a)
     a.norms = ctx->dNorms;
     a.bigLeaves = ctx->dBigLeaves;
     a.filters = ctx->dFilters;
+    a.chunks = ctx->dChunks;
+    a.nChunks = ctx->nChunks;
+    a.nFiltered = ctx->nFiltered;
+    a.extWords = ctx->extWords;
     a.filterMaxOrigin = ctx->filterMaxOrigin;
     a.nSpheres = ctx->nSpheres;
     a.nModels = ctx->nModels;
@@ -886,14 +990,17 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
     fill_args(ctx, frame0, nFrames, a);
     const int tiles = a.tilesX * a.tilesY;
     if (tiles == 0) return RT_OK;
-    const size_t stackBytes = (size_t)(ctx->stackEntries + RT_PIXEL_FIELDS) * RT_WAVE * sizeof(uint32_t);
+    const size_t stackBytes = (size_t)(ctx->stackEntries + RT_PIXEL_FIELDS + (ctx->extWords ? 1 + ctx->extWords : 0)) * RT_WAVE * sizeof(uint32_t);
     a.stackEntries = ctx->stackEntries;
+    const bool many = ctx->nChunks > 0 && !ctx->flatScene;
     void (*kern)(const KArgs) = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_kernel<true, true> : rtk::rt_trace_kernel<false, true>)
+                                : many         ? (ctx->stats ? rtk::rt_trace_kernel<true, false, true> : rtk::rt_trace_kernel<false, false, true>)
                                                : (ctx->stats ? rtk::rt_trace_kernel<true, false> : rtk::rt_trace_kernel<false, false>);
     /* the same code under a second name for the two-launches-per-frame form (see rt_kernels.h) */
     void (*kernHalf)(const KArgs) = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_half_kernel<true, true> : rtk::rt_trace_half_kernel<false, true>)
+                                    : many         ? (ctx->stats ? rtk::rt_trace_half_kernel<true, false, true> : rtk::rt_trace_half_kernel<false, false, true>)
                                                    : (ctx->stats ? rtk::rt_trace_half_kernel<true, false> : rtk::rt_trace_half_kernel<false, false>);
-    const int variant = (ctx->flatScene ? 2 : 0) + (ctx->stats ? 1 : 0);
+    const int variant = (ctx->flatScene ? 2 : many ? 4 : 0) + (ctx->stats ? 1 : 0);
     if (ctx->occBytes[variant] != stackBytes + 1) { /* occupancy query cached per (variant, LDS bytes) */
         int perCU = 0;
         HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, RT_WAVE, stackBytes));

@@ -72,6 +72,20 @@ struct DFilter {
     uint32_t always;
     uint32_t innerRoot;
 };
+/* Two-level model hierarchy for scenes with more than 64 models (the "TLAS" of SURVEY.md §8(f)): models
+ * are clustered in space (Morton order of their filter boxes) into chunks of up to 16; a chunk carries the
+ * union of its members' filter boxes.  The lockstep filter first tests the chunk box and skips all 16 members
+ * when no lane of the wave hits it.  Members are visited later in MODEL-INDEX order (bit masks), so the
+ * clustering never changes results.  96 B, scalar-loaded. */
+#define RT_CHUNK_MODELS 16
+struct DChunk {
+    float bMin[3], bMax[3];
+    uint32_t always;      /* a member cannot be filtered: the chunk box is meaningless */
+    uint32_t count;
+    uint32_t innerRoots;  /* members whose root is an inner node (exact counters of skipped chunks) */
+    uint32_t pad[3];
+    uint32_t members[RT_CHUNK_MODELS];
+};
 struct DMaterial {
     float diffuseCol[4], emissionCol[4], specularCol[4], absorption[4];
     float absorptionStrength, emissionStrength, smoothness, specularProbability;
@@ -94,6 +108,12 @@ struct KArgs {
     const DFilter* filters;      /* one per model */
     float filterMaxOrigin;       /* ray origins farther than this from 0 skip the filter */
     int32_t nSpheres, nModels;
+    /* models [0, nFiltered) go through the conservative filter.  nModels <= 64: bit m of the lane's 64-bit
+     * candidate mask is model m.  More models: bits 0..62 = models 0..62, bit 63 = "more candidates in the LDS
+     * extension" ([1 + extWords][64] after the pixel bookkeeping: a summary word, then 32 models per word,
+     * word k = models 63+32k ..), filled chunk by chunk (DChunk) */
+    const DChunk* chunks;
+    int32_t nChunks, nFiltered, extWords;
     /* render targets: rows owned by this context, packed */
     float* frameRender;
     float* accumulated;

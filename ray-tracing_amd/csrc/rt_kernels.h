@@ -239,8 +239,8 @@ struct Trav {
     bool cull;
 };
 
-template <bool STATS, bool FLAT>
-__device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f3 rdir, SceneHit& h, Trav& t, Stats& st)
+template <bool STATS, bool FLAT, bool MANY>
+__device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* extBase, SceneHit& h, Trav& t, Stats& st)
 {
     h.dst = RT_INF;
     h.obj = -1;
@@ -333,11 +333,12 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
      * (the stats build counts any exact-keep / filter-reject disagreement: must be 0). */
     unsigned long long cand = 0;
     const RT_CAS DFilter* cf = (const RT_CAS DFilter*)a.filters;
-    const int nf = FLAT ? 0 : (a.nModels < 64 ? a.nModels : 64);
+    const int nf = FLAT ? 0 : (MANY ? a.nFiltered : (a.nModels < 64 ? a.nModels : 64));
     if (nf > 0) {
         const rt_f3 winv = rt_v3(__builtin_amdgcn_rcpf(rdir.x), __builtin_amdgcn_rcpf(rdir.y), __builtin_amdgcn_rcpf(rdir.z));
         const bool farOrigin = !(rt_abs(rpos.x) <= a.filterMaxOrigin && rt_abs(rpos.y) <= a.filterMaxOrigin && rt_abs(rpos.z) <= a.filterMaxOrigin);
-        for (int m = 0; m < nf; m++) {
+        /* one model: conservative world-box test, the stats build audits every rejection against the exact root step */
+        auto test_model = [&](int m) -> bool {
             const RT_CAS DFilter& F = cf[m];
             bool keep = true;
             if (!F.always) {
@@ -363,7 +364,40 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
                     if (box_dst(lpos, linv, pa0, pa1) < h.dst || box_dst(lpos, linv, pb0, pb1) < h.dst) st.filterViolations++;
                 }
             }
-            cand |= (keep ? 1ull : 0ull) << m;
+            return keep;
+        };
+        if (!MANY) { /* up to 64 models: one lockstep loop, bit m = model m */
+            for (int m = 0; m < nf; m++) cand |= (test_model(m) ? 1ull : 0ull) << m;
+        } else {
+            /* more than 64 models: chunk boxes first (a chunk no lane of the wave hits costs one box test instead of
+             * 16), candidates beyond model 62 go to the lane's LDS extension words */
+            for (int w = 0; w <= a.extWords; w++) extBase[w * RT_WAVE] = 0u;
+            const RT_CAS DChunk* cc = (const RT_CAS DChunk*)a.chunks;
+            for (int c = 0; c < a.nChunks; c++) {
+                const RT_CAS DChunk& C = cc[c];
+                bool hitC = true;
+                if (!C.always) {
+                    float bMin[3] = {C.bMin[0], C.bMin[1], C.bMin[2]}, bMax[3] = {C.bMax[0], C.bMax[1], C.bMax[2]};
+                    const float dB = box_dst(rpos, winv, bMin, bMax);
+                    hitC = farOrigin || (dB < RT_INF && dB <= h.dst);
+                }
+                /* (the stats build walks every chunk so that the per-model audit sees every rejection) */
+                if (!STATS && __ballot(hitC) == 0ull) continue;
+                const int n = (int)C.count;
+                for (int k = 0; k < n; k++) {
+                    const int m = (int)C.members[k];
+                    const bool keep = test_model(m);
+                    if (STATS && keep && !hitC) st.filterViolations++; /* the chunk box must contain its members' boxes */
+                    if (m < 63) {
+                        cand |= (keep ? 1ull : 0ull) << m;
+                    } else if (keep) {
+                        const int w = (m - 63) >> 5;
+                        extBase[(1 + w) * RT_WAVE] |= 1u << ((m - 63) & 31);
+                        extBase[0] |= 1u << w;
+                        cand |= 1ull << 63;
+                    }
+                }
+            }
         }
     }
     if (STATS) st.model += (uint32_t)a.nModels;
@@ -394,8 +428,8 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
  * the stragglers keep their state in `t`/`h`/LDS and resume at the next call.  The loop has a
  * single, wave-uniform exit (finished lanes park in RT_CODE_DONE instead of leaving one by
  * one), which keeps the loop-carried state in one set of registers. */
-template <bool STATS, bool SUSPEND>
-__device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, SceneHit& h, Trav& t, Stats& st)
+template <bool STATS, bool SUSPEND, bool MANY>
+__device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, uint32_t* extBase, SceneHit& h, Trav& t, Stats& st)
 {
     const DModel* __restrict__ models = a.models;
     const DPair* __restrict__ pairs = a.pairs;
@@ -415,7 +449,7 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
 #define RT_TRAV_VOTE()                                                                                         \
     do {                                                                                                       \
         /* a lane between models that has no model left is done: no more demand for phase A */              \
-        if (t.cur == RT_CODE_NEXT_MODEL && !t.cand && (t.m < 63 ? 64 : t.m + 1) >= a.nModels) t.cur = RT_CODE_DONE; \
+        if (t.cur == RT_CODE_NEXT_MODEL && !t.cand && (MANY ? (t.m < a.nFiltered - 1 ? a.nFiltered : t.m + 1) : (t.m < 63 ? 64 : t.m + 1)) >= a.nModels) t.cur = RT_CODE_DONE; \
         atNext = t.cur == RT_CODE_NEXT_MODEL;                                                                  \
         atLeaf = (t.cur & RT_CODE_LEAF) != 0;                                                                  \
         atInner = t.cur < RT_CODE_DONE; /* leaf codes have bit 31 set */                                       \
@@ -425,12 +459,26 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
     if ((nA + nB + nC) * RT_SUSPEND_DEN > enteredNum) do {
         if (nA >= nB && nA >= nC) {
             if (atNext) { /* ---- A: next model, RC:349-355 */
-                /* the filtered candidates among [0,64), then any model >= 64 in order */
-                if (t.cand) {
-                    t.m = __ffsll((long long)t.cand) - 1;
+                /* the filtered candidates in model order (register mask, then the LDS extension words of scenes
+                 * with more than 64 models), then any model beyond the filtered range in order */
+                const unsigned long long regBits = MANY ? (t.cand & 0x7fffffffffffffffull) : t.cand;
+                if (regBits) {
+                    t.m = __ffsll((long long)regBits) - 1;
                     t.cand &= t.cand - 1;
+                } else if (MANY && t.cand) { /* bit 63 alone: the next candidate is in the extension */
+                    uint32_t summary = extBase[0];
+                    const int w = __ffs((int)summary) - 1;
+                    uint32_t word = extBase[(1 + w) * RT_WAVE];
+                    t.m = 63 + 32 * w + (__ffs((int)word) - 1);
+                    word &= word - 1;
+                    extBase[(1 + w) * RT_WAVE] = word;
+                    if (!word) {
+                        summary &= summary - 1;
+                        extBase[0] = summary;
+                        if (!summary) t.cand = 0;
+                    }
                 } else {
-                    t.m = t.m < 63 ? 64 : t.m + 1;
+                    t.m = MANY ? (t.m < a.nFiltered - 1 ? a.nFiltered : t.m + 1) : (t.m < 63 ? 64 : t.m + 1);
                     if (STATS && !(models[t.m].rootCode & RT_CODE_LEAF)) st.inner++;
                 }
                 t.rootStep = true;
@@ -552,11 +600,16 @@ __device__ __forceinline__ void traverse_flat(const KArgs& a, rt_f3 rpos, rt_f3 
 
 /* Run-to-completion form (debug hook). */
 template <bool STATS>
-__device__ __forceinline__ void intersect_scene(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, SceneHit& h, Stats& st)
+__device__ __forceinline__ void intersect_scene(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, uint32_t* extBase, SceneHit& h, Stats& st)
 {
     Trav t;
-    begin_intersect<STATS, false>(a, rpos, rdir, h, t, st);
-    traverse<STATS, false>(a, rpos, rdir, stackBase, h, t, st);
+    if (a.nChunks) { /* wave-uniform: more than 64 models */
+        begin_intersect<STATS, false, true>(a, rpos, rdir, extBase, h, t, st);
+        traverse<STATS, false, true>(a, rpos, rdir, stackBase, extBase, h, t, st);
+    } else {
+        begin_intersect<STATS, false, false>(a, rpos, rdir, extBase, h, t, st);
+        traverse<STATS, false, false>(a, rpos, rdir, stackBase, extBase, h, t, st);
+    }
 }
 
 /* Position and world normal of the winning hit: RC:319-320 (sphere) or RC:208-209 +
@@ -613,7 +666,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
  * LDS: the per-lane traversal stack, [level][lane], sized by the host to the deepest
  * BVH of the scene (dynamic shared memory).
  * ------------------------------------------------------------------------- */
-template <bool STATS, bool FLAT>
+template <bool STATS, bool FLAT, bool MANY>
 __device__ __forceinline__ void trace_body(const KArgs& a)
 {
     extern __shared__ uint32_t s_stack[];
@@ -658,6 +711,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
      * traversal stack ([field][lane], conflict free), not in VGPRs: it would otherwise be carried
      * through — and spilled around — the traversal and shading code. */
     uint32_t* const pxu = &s_stack[(size_t)cold_args().stackEntries * RT_WAVE + lane];
+    uint32_t* const extBase = pxu + RT_PIXEL_FIELDS * RT_WAVE; /* candidate-mask extension, scenes with more than 64 models */
     float* const pxf = reinterpret_cast<float*>(pxu);
     enum { PX_INDEX = 0, PX_LINEAR, PX_SEGSTART, PX_FRAME, PX_SAMPLE, PX_FPX, PX_FPY, PX_FPZ, PX_TIX, PX_TIY, PX_TIZ };
 #define PXU(k) pxu[(k) * RT_WAVE]
@@ -796,13 +850,13 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
             }
             if (pathActive) {
                 phase_mark<STATS>(st, PH_SPHERES);
-                begin_intersect<STATS, FLAT>(a, rpos, rdir, h, t, st);
+                begin_intersect<STATS, FLAT, MANY>(a, rpos, rdir, extBase, h, t, st);
                 segments++;
                 inTrav = true;
                 if (FLAT) traverse_flat<STATS>(a, rpos, rdir, h, st);
             }
         }
-        if (inTrav && (FLAT || traverse<STATS, true>(a, rpos, rdir, stackBase, h, t, st))) {
+        if (inTrav && (FLAT || traverse<STATS, true, MANY>(a, rpos, rdir, stackBase, extBase, h, t, st))) {
             inTrav = false;
             /* the rest of one iteration of Trace's bounce loop — RC:488-538 */
             bool endPath = false;
@@ -909,28 +963,30 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
  * into while the context runs on its own streams (rt_context.hip, launch_frames) — the same code, so
  * that profilers list the two kinds of dispatch, whose durations mean different things (the halves
  * overlap in time), separately. */
-template <bool STATS, bool FLAT>
+/* MANY: scenes with more than 64 models (two-level filter, candidate masks extended into LDS) — a separate
+ * instantiation so that the common case keeps its registers */
+template <bool STATS, bool FLAT, bool MANY = false>
 __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kernel(const KArgs a)
 {
-    trace_body<STATS, FLAT>(a);
+    trace_body<STATS, FLAT, MANY>(a);
 }
-template <bool STATS, bool FLAT>
+template <bool STATS, bool FLAT, bool MANY = false>
 __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_half_kernel(const KArgs a)
 {
-    trace_body<STATS, FLAT>(a);
+    trace_body<STATS, FLAT, MANY>(a);
 }
 
 /* ---- test hooks (rt_debug_*): the same device functions, one ray / value per lane */
 __global__ void __launch_bounds__(RT_WAVE) rt_debug_intersect_kernel(const KArgs a, const float* origins, const float* dirs, int n, float* out)
 {
-    __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_WAVE];
+    __shared__ uint32_t s_stack[(RT_STACK_DEPTH + 33) * RT_WAVE]; /* stack + candidate-mask extension (summary + 32 words) */
     int i = blockIdx.x * RT_WAVE + threadIdx.x;
     if (i >= n) return;
     rt_f3 o = rt_v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
     rt_f3 d = rt_v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
     SceneHit h;
     Stats st = {};
-    intersect_scene<false>(a, o, d, &s_stack[threadIdx.x], h, st);
+    intersect_scene<false>(a, o, d, &s_stack[threadIdx.x], &s_stack[RT_STACK_DEPTH * RT_WAVE + threadIdx.x], h, st);
     float* r = out + 10 * i;
     for (int k = 0; k < 10; k++) r[k] = 0.0f;
     r[2] = h.dst;

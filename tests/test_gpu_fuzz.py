@@ -87,7 +87,8 @@ def crowded_scene(pkg, n_models, n_spheres, seed=7):
     return pkg.scenes.SceneDescription("crowded", 88, 48, 2, settings, cam, models, spheres)
 
 
-@pytest.mark.parametrize("n_models,n_spheres,quality", [(64, 32, 1), (65, 33, 1), (97, 70, 0), (3, 64, 1), (70, 5, 2)])
+@pytest.mark.parametrize("n_models,n_spheres,quality", [(64, 32, 1), (65, 33, 1), (97, 70, 0), (3, 64, 1), (70, 5, 2),
+                                                        (200, 4, 1), (333, 0, 0)])
 def test_more_models_and_spheres_than_one_mask_word(pkg, api, orc, n_models, n_spheres, quality):
     out = []
     for lib, tr in ((api, api.create_tracer(0)), (orc, orc.create_tracer(8))):
@@ -107,6 +108,32 @@ def test_more_models_and_spheres_than_one_mask_word(pkg, api, orc, n_models, n_s
     assert (a.view(np.uint32) == b.view(np.uint32)).all()
     assert ca == cb and viol == 0
     assert ca[KEYS.index("modelVisits")] == ca[KEYS.index("segments")] * n_models
+
+
+def test_two_level_model_hierarchy_follows_moving_models(pkg, api, orc):
+    """200 models (two-level chunked filter, candidate masks in LDS): models move between frames, so the
+    filter boxes, the chunk boxes and the spatial clustering are rebuilt and uploaded stream-ordered by
+    rt_update_models; every frame must still equal the oracle (which simply walks all 200 models)."""
+    out = []
+    for lib, tr in ((api, api.create_tracer(0)), (orc, orc.create_tracer(8))):
+        sc = crowded_scene(pkg, 200, 3, seed=21)
+        if lib is api:
+            tr.enable_stats(True)
+        mgr = sc.make_manager(tr, lib)
+        mgr.OnEnable(renderSeed=5)
+        for f in range(4):
+            for i, m in enumerate(mgr.models):
+                if i % 3 == f % 3:   # a third of the models jump somewhere else each frame
+                    p = m.transform.position
+                    m.transform.position = (p[0] + 0.37 * ((i % 7) - 3), p[1], p[2] - 0.21 * ((i % 5) - 2))
+            mgr.RenderFrame()
+        c = tr.counters()
+        viol = tr.phase_profile()["filter_violations"][0] if lib is api else 0
+        out.append((tr.read_accumulated(), [c[k] for k in KEYS], viol))
+        tr.close()
+    (a, ca, viol), (b, cb, _) = out
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    assert ca == cb and viol == 0
 
 
 @pytest.mark.parametrize("seed", range(6))

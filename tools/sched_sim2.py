@@ -13,6 +13,9 @@ COST = dict(A=149, B=99, C=121, VOTE=35, GLASS=670, RAYGEN=310, BEGIN=230, SHADE
 SPP = 8
 
 
+DEPTHS = {}  # id(token list) -> stack entries held while waiting for each token
+
+
 def parse(npz):
     z = np.load(npz)
     data, offs = z["data"], z["offs"]
@@ -29,21 +32,27 @@ def parse(npz):
                 i += 1
             elif t == 83:  # S: segment
                 i += 1
-                toks, model = [], None
+                toks, model, deps, depth = [], None, [], []
                 while i < n and b[i] in (65, 66, 67):
                     if b[i] == 65:
                         if model is not None and model != ["A", "B"]:
                             toks += model
+                            deps += depth
                         model = ["A"]
+                        depth = [0]
                         i += 1
                     elif b[i] == 66:
                         model.append("B")
-                        i += 1
+                        depth.append(b[i + 1])
+                        i += 2
                     else:
                         model.append(b[i + 1])  # leaf with n tests (int)
-                        i += 2
+                        depth.append(b[i + 2])
+                        i += 3
                 if model is not None and model != ["A", "B"]:
                     toks += model
+                    deps += depth
+                DEPTHS[id(toks)] = deps
                 outcome = chr(b[i]) if i < n and b[i] in (75, 79, 71) else "E"
                 if outcome != "E":
                     i += 1
@@ -482,7 +491,7 @@ if __name__ == "__main__":
         print(f"       -> x{b / k:.2f}")
 
 
-def sim_sorted(pixels, tiles_total, NW=4, every=4, sort_cost=45, burst=3):
+def sim_sorted(pixels, tiles_total, NW=4, every=4, sort_cost=45, burst=3, budget=0, timing=None):
     """NW waves of one workgroup; every `every` iterations all rays of the workgroup are re-sorted by the
     phase they want next (state moved through LDS, `sort_cost` instructions per wave) and dealt out in
     runs of 64; between sorts each wave executes the phase most of its lanes want."""
@@ -505,6 +514,14 @@ def sim_sorted(pixels, tiles_total, NW=4, every=4, sort_cost=45, burst=3):
     for c in lanes:
         c.lit = False
     it = 0
+    wcost = [0.0] * NW   # instructions each wave issued in the current epoch
+    simd_time = 0.0      # sum over epochs of the slowest SIMD (waves w and w + NW/2 share one)
+    def close_epoch():
+        nonlocal simd_time
+        half = max(1, NW // 2)
+        simd_time += max(wcost[i] + (wcost[i + half] if i + half < NW else 0) for i in range(half))
+        for i in range(NW):
+            wcost[i] = 0.0
     while True:
         idle = [c for c in lanes if c.state == "D"]
         if idle and pool:
@@ -518,10 +535,16 @@ def sim_sorted(pixels, tiles_total, NW=4, every=4, sort_cost=45, burst=3):
         if all(c.state == "D" for c in lanes):
             break
         if every and it % every == 0:
+            close_epoch()
             lanes.sort(key=lambda c: (order + "Z").index(want(c)))
             acc.run("SORT", sum(1 for c in lanes if c.state != "D"), cost=sort_cost, mult=NW)
+            for i in range(NW):
+                wcost[i] += sort_cost
         it += 1
         for w in range(NW):
+            if budget and wcost[w] >= budget:
+                continue  # this wave already waits at the barrier
+            before = sum(acc.cost.values())
             wl = lanes[w * 64:(w + 1) * 64]
             by = {}
             for c in wl:
@@ -575,6 +598,12 @@ def sim_sorted(pixels, tiles_total, NW=4, every=4, sort_cost=45, burst=3):
                 for c in served:
                     c.begin()
                     acc.segments += 1
+            wcost[w] += sum(acc.cost.values()) - before
+        if budget and all(wcost[w] >= budget or not any(c.state != "D" for c in lanes[w * 64:(w + 1) * 64]) for w in range(NW)):
+            it = 0  # everybody reached the barrier: sort at the top of the next round
+    close_epoch()
+    if timing is not None:
+        timing["simd_instr_per_64seg"] = 32.0 * NW * simd_time / max(1, acc.segments)  # comparable with instr / 64 segments of one wave
     return acc
 
 
@@ -587,7 +616,7 @@ if __name__ == "__main__":
             print(f"       -> x{b / k:.2f}")
 
 
-def sim_colpool(pixels, tiles_total, NW=8, PJ=4, swap_cost=22, vote_cost=45, burst=3, weight=False):
+def sim_colpool(pixels, tiles_total, NW=8, PJ=4, swap_cost=22, vote_cost=45, burst=3, weight=False, empty_stack_only=False):
     """Lock-free ray pool: NW waves hold one ray per lane in registers; PJ x 64 more rays are parked in LDS,
     slot (j, col).  Lane l only ever swaps with the PJ slots of column l (bank-conflict-free).  Each iteration a
     wave picks the phase X that the most lanes could serve (own ray wants X, or a parked X-ray in the column),
@@ -633,7 +662,9 @@ def sim_colpool(pixels, tiles_total, NW=8, PJ=4, swap_cost=22, vote_cost=45, bur
                 ps = set()
                 if ownw[l] is not None:
                     ps.add(ownw[l])
-                for j in range(PJ):
+                o = wl[l]
+                locked = empty_stack_only and o.state == "T" and DEPTHS[id(o.toks)][o.pos] > 0
+                for j in range(0 if locked else PJ):
                     p = want(park[j][l])
                     if p is not None:
                         ps.add(p)
@@ -645,6 +676,9 @@ def sim_colpool(pixels, tiles_total, NW=8, PJ=4, swap_cost=22, vote_cost=45, bur
             best = max(cnt, key=lambda p: cnt[p] * Wt[p])
             nsw = 0
             for l in range(64):
+                o = wl[l]
+                if empty_stack_only and o.state == "T" and DEPTHS[id(o.toks)][o.pos] > 0:
+                    continue  # a ray with entries on its lane's traversal stack stays with that lane
                 if ownw[l] != best:
                     for j in range(PJ):
                         if want(park[j][l]) == best:
