@@ -484,9 +484,14 @@ static void make_filters(const RtModel* models, int n_models, const std::vector<
     for (int i = 0; i < n_models; i++) {
         DFilter& f = out[i];
         memset(&f, 0, sizeof(f));
-        f.innerRoot = (rootCodes[i] & RT_CODE_LEAF) ? 0u : 1u;
+        /* innerRoot: bit 0 = the root is an inner node; a leaf root carries its triangle count in bits 8.. (exact
+         * counters of rejected models).  rootChildren holds the root's two child boxes, or — leaf root — the
+         * bounds of the leaf's triangles twice (computed from the triangles on upload, never taken from the
+         * root node, whose bounds the reference does not read) */
+        const bool leafRoot = (rootCodes[i] & RT_CODE_LEAF) != 0;
+        f.innerRoot = leafRoot ? ((uint32_t)rootChildren[2 * (size_t)i].triangleCount << 8) : 1u;
         f.always = 1;
-        if (!f.innerRoot) continue;
+        if (leafRoot && rootChildren[2 * (size_t)i].triangleCount <= 0) continue; /* no box available */
         double wmin[2][3], wmax[2][3];
         if (!world_boxes(models[i], &rootChildren[2 * (size_t)i], wmin, wmax, &lr[i])) continue;
         ok[i] = 1;
@@ -576,7 +581,7 @@ static void make_chunks(const std::vector<DFilter>& filters, std::vector<DChunk>
         while (p < order.size() && c.count < RT_CHUNK_MODELS && (filters[order[p].second].always != 0) == alw) {
             const DFilter& f = filters[order[p].second];
             c.members[c.count++] = (uint32_t)order[p].second;
-            c.innerRoots += f.innerRoot;
+            c.innerRoots += f.innerRoot & 1u;
             if (!alw)
                 for (int d = 0; d < 3; d++) {
                     c.bMin[d] = fminf(c.bMin[d], f.bMin[d]);
@@ -763,6 +768,24 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
         if (!(rootCodes[i] & RT_CODE_LEAF)) {
             rootChildren[2 * (size_t)i] = nodes[m.nodeOffset + root.startIndex];
             rootChildren[2 * (size_t)i + 1] = nodes[m.nodeOffset + root.startIndex + 1];
+        } else { /* leaf root: the bounds of its triangles (validated by leaf_code above), count in triangleCount */
+            RtBVHNode b;
+            memset(&b, 0, sizeof(b));
+            for (int d = 0; d < 3; d++) { b.boundsMin[d] = INFINITY; b.boundsMax[d] = -INFINITY; }
+            bool fin = true;
+            for (int t = 0; t < root.triangleCount; t++) {
+                const RtTriangle& tr = triangles[(size_t)m.triOffset + root.startIndex + t];
+                const float* vs[3] = {tr.posA, tr.posB, tr.posC};
+                for (int v = 0; v < 3; v++)
+                    for (int d = 0; d < 3; d++) {
+                        fin = fin && std::isfinite(vs[v][d]);
+                        b.boundsMin[d] = fminf(b.boundsMin[d], vs[v][d]);
+                        b.boundsMax[d] = fmaxf(b.boundsMax[d], vs[v][d]);
+                    }
+            }
+            b.triangleCount = (fin && root.triangleCount < (1 << 23)) ? root.triangleCount : 0; /* 0 = never filtered */
+            rootChildren[2 * (size_t)i] = b;
+            rootChildren[2 * (size_t)i + 1] = b;
         }
     }
 

@@ -348,8 +348,25 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
                 keep = farOrigin || (dB < RT_INF && dB <= h.dst);
             }
             if (STATS) {
-                st.inner += F.innerRoot;
-                if (F.innerRoot && !keep) { /* audit the conservative filter against the exact root step */
+                st.inner += F.innerRoot & 1u;
+                if (!(F.innerRoot & 1u) && !keep) { /* a rejected leaf-root model: the reference would have run its tests */
+                    st.leaf++;
+                    st.tri += F.innerRoot >> 8;
+                    const RT_CAS DModel& M = ((const RT_CAS DModel*)a.models)[m];
+                    rt_f3 lpos = rt_v3(M.w2l[0] * rpos.x + M.w2l[1] * rpos.y + M.w2l[2] * rpos.z + M.w2l[3] * 1.0f,
+                                       M.w2l[4] * rpos.x + M.w2l[5] * rpos.y + M.w2l[6] * rpos.z + M.w2l[7] * 1.0f,
+                                       M.w2l[8] * rpos.x + M.w2l[9] * rpos.y + M.w2l[10] * rpos.z + M.w2l[11] * 1.0f);
+                    rt_f3 ldir = rt_v3(M.w2l[0] * rdir.x + M.w2l[1] * rdir.y + M.w2l[2] * rdir.z + M.w2l[3] * 0.0f,
+                                       M.w2l[4] * rdir.x + M.w2l[5] * rdir.y + M.w2l[6] * rdir.z + M.w2l[7] * 0.0f,
+                                       M.w2l[8] * rdir.x + M.w2l[9] * rdir.y + M.w2l[10] * rdir.z + M.w2l[11] * 0.0f);
+                    uint32_t count = (M.rootCode >> 24) & 0x7fu, start = M.rootCode & RT_CODE_MAX_INLINE_START;
+                    if (count == 0) { count = a.bigLeaves[2 * start + 1]; start = a.bigLeaves[2 * start]; }
+                    float best = h.dst, bu, bv, bdet;
+                    int btri = -1;
+                    for (uint32_t i = 0; i < count; i++) tri_test(a.tris, M.triBase + (int)start + (int)i, lpos, ldir, M.cullBackface != 0, best, btri, bu, bv, bdet);
+                    if (btri >= 0) st.filterViolations++; /* audit: a rejected model must not hold a closer hit */
+                }
+                if ((F.innerRoot & 1u) && !keep) { /* audit the conservative filter against the exact root step */
                     const RT_CAS DModel& M = ((const RT_CAS DModel*)a.models)[m];
                     rt_f3 lpos = rt_v3(M.w2l[0] * rpos.x + M.w2l[1] * rpos.y + M.w2l[2] * rpos.z + M.w2l[3] * 1.0f,
                                        M.w2l[4] * rpos.x + M.w2l[5] * rpos.y + M.w2l[6] * rpos.z + M.w2l[7] * 1.0f,
