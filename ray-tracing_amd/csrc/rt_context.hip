@@ -1004,6 +1004,16 @@ static void fill_args(RtContext* ctx, int frame0, int nFrames, KArgs& a)
     a.rcpHm1 = rt_rcp((float)a.H - 1.0f);
     a.rcpW = rt_rcp((float)a.W);
     a.rcpSpp = rt_rcp((float)a.spp);
+    {
+        /* x + (+-0) == x bit for bit unless x is -0 (then the sign of the sum follows the random jitter's sign):
+         * the kernel may skip the defocus jitter's sin/cos/sqrt when no component of the camera origin — computed
+         * here with the kernel's own rt_mul_point — is a negative zero */
+        bool fin = true;
+        for (int k = 0; k < 16; k++) fin = fin && std::isfinite(a.cam[k]);
+        const rt_f3 o = rt_mul_point(a.cam, rt_v3(0.0f, 0.0f, 0.0f), 1.0f);
+        const bool noNegZero = rt_f2u(o.x) != 0x80000000u && rt_f2u(o.y) != 0x80000000u && rt_f2u(o.z) != 0x80000000u;
+        a.raygenNoDefocus = (a.defocus == 0.0f && fin && noNegZero && std::isfinite(a.rcpW)) ? 1 : 0;
+    }
     a.counters = ctx->dCounters;
 }
 

@@ -850,8 +850,19 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     const rt_f3 camRight = rt_v3(cam[0], cam[1], cam[2]);
                     const rt_f3 camUp = rt_v3(cam[4], cam[5], cam[6]);
                     const float invNumPixelsX = c.rcpW; /* x / numPixels.x */
-                    rt_f2 dj = rand_circle(&rng);
-                    rt_f3 rayOrigin = camOrigin + camRight * (dj.x * c.defocus * invNumPixelsX) + camUp * (dj.y * c.defocus * invNumPixelsX);
+                    rt_f3 rayOrigin;
+                    if (c.raygenNoDefocus) {
+                        /* defocusStrength == 0 (every BASELINE scene but config 4): the jitter terms are
+                         * camRight * (+-0) + camUp * (+-0), and x + (+-0) == x bit for bit unless x is -0, which the
+                         * host excluded for the camera origin — only the two random draws of RandomPointInCircle
+                         * (RC:159-164) remain, its sin/cos/sqrt are never observed */
+                        rt_next_random(&rng);
+                        rt_next_random(&rng);
+                        rayOrigin = camOrigin;
+                    } else {
+                        rt_f2 dj = rand_circle(&rng);
+                        rayOrigin = camOrigin + camRight * (dj.x * c.defocus * invNumPixelsX) + camUp * (dj.y * c.defocus * invNumPixelsX);
+                    }
                     rt_f2 jj = rand_circle(&rng);
                     const rt_f3 focusPoint = rt_v3(PXF(PX_FPX), PXF(PX_FPY), PXF(PX_FPZ));
                     rt_f3 jfp = focusPoint + camRight * (jj.x * c.diverge * invNumPixelsX) + camUp * (jj.y * c.diverge * invNumPixelsX);
