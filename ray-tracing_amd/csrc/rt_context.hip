@@ -1023,7 +1023,12 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
     fill_args(ctx, frame0, nFrames, a);
     const int tiles = a.tilesX * a.tilesY;
     if (tiles == 0) return RT_OK;
-    const size_t stackBytes = (size_t)(ctx->stackEntries + RT_PIXEL_FIELDS + (ctx->extWords ? 1 + ctx->extWords : 0)) * RT_WAVE * sizeof(uint32_t);
+#ifdef RT_LDS_NODE_FETCH
+    const size_t slabBytes = 4 * RT_WAVE * 16; /* experiment: LDS-staged node fetch (rt_kernels.h) */
+#else
+    const size_t slabBytes = 0;
+#endif
+    const size_t stackBytes = (size_t)(ctx->stackEntries + RT_PIXEL_FIELDS + (ctx->extWords ? 1 + ctx->extWords : 0)) * RT_WAVE * sizeof(uint32_t) + slabBytes;
     a.stackEntries = ctx->stackEntries;
     const bool many = ctx->nChunks > 0 && !ctx->flatScene;
     void (*kern)(const KArgs) = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_kernel<true, true> : rtk::rt_trace_kernel<false, true>)

@@ -448,6 +448,10 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
 template <bool STATS, bool SUSPEND, bool MANY>
 __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, uint32_t* extBase, SceneHit& h, Trav& t, Stats& st)
 {
+#ifdef RT_LDS_NODE_FETCH
+    /* 4 KB slab after [stack][pixel fields][mask extension]; wave-uniform address */
+    uint32_t* const nodeSlab = (extBase - (threadIdx.x & 63)) + (a.extWords ? 1 + a.extWords : 0) * RT_WAVE;
+#endif
     const DModel* __restrict__ models = a.models;
     const DPair* __restrict__ pairs = a.pairs;
     const DTri* __restrict__ tris = a.tris;
@@ -526,8 +530,26 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
                 if (STATS && !t.rootStep) st.inner++;
                 t.rootStep = false;
                 phase_mark<STATS>(st, PH_INNER);
+#ifndef RT_LDS_NODE_FETCH
                 const float4* q = reinterpret_cast<const float4*>(pairs + t.cur);
                 const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+#else
+                /* EXPERIMENT kept reproducible (make lds-fetch; profiles/r02_lds_node_fetch.txt): the north_star's
+                 * "BVH nodes staged through LDS" as the hardware offers it — the node's four 16-B quarters go
+                 * straight from L2 into an LDS slab with global_load_lds_dwordx4 (destination = wave-uniform base +
+                 * lane*16, so the slab is [quarter][lane]) and are read back with ds_read_b128.  Bit-identical,
+                 * measured slower: the kernel is VALU-issue bound (profiles/r02_occupancy_sweep.txt), the fetch is a
+                 * dependent pointer chase with nothing to overlap, and the slab costs 4 KB of LDS per wave. */
+                {
+                    const char* g = reinterpret_cast<const char*>(pairs + t.cur);
+                    for (int qq = 0; qq < 4; qq++)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 16 * qq),
+                                                         (__attribute__((address_space(3))) void*)(nodeSlab + qq * RT_WAVE * 4), 16, 0, 0);
+                    __builtin_amdgcn_s_waitcnt(0); /* vmcnt(0) lgkmcnt(0) */
+                }
+                const float4* qs = reinterpret_cast<const float4*>(nodeSlab) + (threadIdx.x & 63);
+                const float4 q0 = qs[0], q1 = qs[RT_WAVE], q2 = qs[2 * RT_WAVE], q3 = qs[3 * RT_WAVE];
+#endif
                 float aMin[3] = {q0.x, q0.y, q0.z}, aMax[3] = {q0.w, q1.x, q1.y};
                 float bMin[3] = {q1.z, q1.w, q2.x}, bMax[3] = {q2.y, q2.z, q2.w};
                 uint32_t codeA = __float_as_uint(q3.x), codeB = __float_as_uint(q3.y);
@@ -1007,7 +1029,7 @@ __global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_half_
 /* ---- test hooks (rt_debug_*): the same device functions, one ray / value per lane */
 __global__ void __launch_bounds__(RT_WAVE) rt_debug_intersect_kernel(const KArgs a, const float* origins, const float* dirs, int n, float* out)
 {
-    __shared__ uint32_t s_stack[(RT_STACK_DEPTH + 33) * RT_WAVE]; /* stack + candidate-mask extension (summary + 32 words) */
+    __shared__ uint32_t s_stack[(RT_STACK_DEPTH + 33 + 16) * RT_WAVE]; /* stack + candidate-mask extension (summary + 32 words) [+ the RT_LDS_NODE_FETCH slab] */
     int i = blockIdx.x * RT_WAVE + threadIdx.x;
     if (i >= n) return;
     rt_f3 o = rt_v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
