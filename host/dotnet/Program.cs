@@ -8,9 +8,9 @@ namespace RayTraceHost
 {
     static class Program
     {
-        static float[] Col(float r, float g, float b, float a = 1) => new[] { r, g, b, a };
+        static Float4 Col(float r, float g, float b, float a = 1) => new Float4(r, g, b, a);
 
-        static RtMaterial Material(float[] diffuse, int flag = 0)
+        static RtMaterial Material(Float4 diffuse, int flag = 0)
         {
             // RayTracingMaterial.SetDefaultValues (RayTracingMaterial.cs:29-38)
             return new RtMaterial {
@@ -35,8 +35,8 @@ namespace RayTraceHost
             var ground = new RtModel {
                 nodeOffset = 0, triOffset = 0,
                 // localToWorld = T(0) * Rx(90deg) * S(40,40,1), column-major; worldToLocal = inverse
-                localToWorld = new float[] { 40, 0, 0, 0,  0, 0, 40, 0,  0, -1, 0, 0,  0, 0, 0, 1 },
-                worldToLocal = new float[] { 0.025f, 0, 0, 0,  0, 0, -1, 0,  0, 0.025f, 0, 0,  0, 0, 0, 1 },
+                localToWorld = new Float4x4(new Float4(40, 0, 0, 0), new Float4(0, 0, 40, 0), new Float4(0, -1, 0, 0), new Float4(0, 0, 0, 1)),
+                worldToLocal = new Float4x4(new Float4(0.025f, 0, 0, 0), new Float4(0, 0, -1, 0), new Float4(0, 0.025f, 0, 0), new Float4(0, 0, 0, 1)),
                 material = Material(Col(0.82f, 0.82f, 0.82f), flag: 1) };
             ground.material.emissionCol = Col(0.28f, 0.28f, 0.33f);
             ground.material.specularProbability = 0;
@@ -47,19 +47,18 @@ namespace RayTraceHost
             {
                 float r = 0.3f + 0.6f * (float)rng.NextDouble();
                 spheres[i] = new RtSphere {
-                    centre = new[] { (i % 4 - 1.5f) * 2.2f, r, (i / 4 - 1.5f) * 2.2f }, radius = r,
+                    centre = new Float3((i % 4 - 1.5f) * 2.2f, r, (i / 4 - 1.5f) * 2.2f), radius = r,
                     material = Material(Col((float)rng.NextDouble(), (float)rng.NextDouble(), (float)rng.NextDouble())) };
             }
             RayTraceNative.Check(ctx, RayTraceNative.rt_upload_scene(ctx, new[] { ground }, 1, tris, 2, nodes, nNodes, spheres, 16));
 
-            var vp = new float[3];
-            RayTraceNative.rt_camera_view_params(60f, (float)W / H, 1f, vp); // RCM:185-188
+            RayTraceNative.rt_camera_view_params(60f, (float)W / H, 1f, out Float3 vp); // RCM:185-188
             var p = new RtParams {
                 abi_version = 1, struct_size = (uint)Marshal.SizeOf<RtParams>(),
                 maxBounceCount = 8, numRaysPerPixel = 8, frame = 1, renderSeed = 1, useSky = 1, accumulate = 1,
                 defocusStrength = 0, divergeStrength = 1.5f, sunFocus = 500, sunIntensity = 10,
-                sunColour = new[] { 1f, 1f, 1f }, dirToSun = new[] { 0f, -1f, 0f }, viewParams = vp,
-                camLocalToWorld = new float[] { 1, 0, 0, 0,  0, 1, 0, 0,  0, 0, 1, 0,  0, 2.6f, -8.8f, 1 } };
+                sunColour = new Float3(1, 1, 1), dirToSun = new Float3(0, -1, 0), viewParams = vp,
+                camLocalToWorld = new Float4x4(new Float4(1, 0, 0, 0), new Float4(0, 1, 0, 0), new Float4(0, 0, 1, 0), new Float4(0, 2.6f, -8.8f, 1)) };
             RayTraceNative.Check(ctx, RayTraceNative.rt_set_params(ctx, ref p));
             RayTraceNative.Check(ctx, RayTraceNative.rt_reset_accumulation(ctx));   // RCM:69-76
 

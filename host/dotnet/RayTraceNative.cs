@@ -1,19 +1,35 @@
 // P/Invoke binding of include/rt_abi.h for a .NET 8 host.
 // UNCOMPILED IN THIS ENVIRONMENT (no dotnet/mono in the image); kept in sync with the header by
-// tests/test_dotnet_layout.py, which parses both.
+// tests/test_dotnet_layout.py, which parses both.  Every struct is BLITTABLE (plain float/int fields only),
+// so RtModel[] / RtTriangle[] / ... are pinned and handed to the library without per-element marshalling.
 using System;
 using System.Runtime.InteropServices;
 
 namespace RayTraceHost
 {
+    // Blittable value types (no marshalling: arrays of these structs are pinned and passed as they are), the
+    // counterparts of the Unity types the reference's own buffers are made of: Color = 4 floats
+    // (RayTracingMaterial.cs:15-27), Vector3 = 3 floats (BVH.cs:579-598), Matrix4x4 = 16 floats in COLUMN-major
+    // memory order m00,m10,m20,m30, m01,... (RayComputeManager.cs:256-263).
+    [StructLayout(LayoutKind.Sequential)]
+    public struct Float3 { public float x, y, z; public Float3(float x, float y, float z) { this.x = x; this.y = y; this.z = z; } }
+    [StructLayout(LayoutKind.Sequential)]
+    public struct Float4 { public float x, y, z, w; public Float4(float x, float y, float z, float w) { this.x = x; this.y = y; this.z = z; this.w = w; } }
+    [StructLayout(LayoutKind.Sequential)]
+    public struct Float4x4
+    {
+        public Float4 c0, c1, c2, c3; // columns
+        public Float4x4(Float4 c0, Float4 c1, Float4 c2, Float4 c3) { this.c0 = c0; this.c1 = c1; this.c2 = c2; this.c3 = c3; }
+    }
+
     // RayTracingMaterial.cs:15-27 == RtMaterial (88 bytes)
     [StructLayout(LayoutKind.Sequential)]
     public struct RtMaterial
     {
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 4)] public float[] diffuseCol;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 4)] public float[] emissionCol;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 4)] public float[] specularCol;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 4)] public float[] absorption;
+        public Float4 diffuseCol;
+        public Float4 emissionCol;
+        public Float4 specularCol;
+        public Float4 absorption;
         public float absorptionStrength;
         public float emissionStrength;
         public float smoothness;
@@ -28,8 +44,8 @@ namespace RayTraceHost
     {
         public int nodeOffset;
         public int triOffset;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 16)] public float[] worldToLocal;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 16)] public float[] localToWorld;
+        public Float4x4 worldToLocal;
+        public Float4x4 localToWorld;
         public RtMaterial material;
     }
 
@@ -37,20 +53,20 @@ namespace RayTraceHost
     [StructLayout(LayoutKind.Sequential)]
     public struct RtTriangle
     {
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public float[] posA;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public float[] posB;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public float[] posC;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public float[] normA;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public float[] normB;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public float[] normC;
+        public Float3 posA;
+        public Float3 posB;
+        public Float3 posC;
+        public Float3 normA;
+        public Float3 normB;
+        public Float3 normC;
     }
 
     // BVH.cs:432-457 == RtBVHNode (32 bytes)
     [StructLayout(LayoutKind.Sequential)]
     public struct RtBVHNode
     {
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public float[] boundsMin;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public float[] boundsMax;
+        public Float3 boundsMin;
+        public Float3 boundsMax;
         public int startIndex;
         public int triangleCount;
     }
@@ -59,7 +75,7 @@ namespace RayTraceHost
     [StructLayout(LayoutKind.Sequential)]
     public struct RtSphere
     {
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public float[] centre;
+        public Float3 centre;
         public float radius;
         public RtMaterial material;
     }
@@ -79,10 +95,10 @@ namespace RayTraceHost
         public float divergeStrength;
         public float sunFocus;
         public float sunIntensity;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public float[] sunColour;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public float[] dirToSun;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public float[] viewParams;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 16)] public float[] camLocalToWorld;
+        public Float3 sunColour;
+        public Float3 dirToSun;
+        public Float3 viewParams;
+        public Float4x4 camLocalToWorld;
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -128,7 +144,24 @@ namespace RayTraceHost
         [DllImport(Lib)] public static extern int rt_build_bvh([In] float[] verts, [In] float[] normals, int n_verts,
             [In] int[] indices, int n_indices, int quality, [Out] RtBVHNode[] out_nodes, out int out_n_nodes,
             [Out] RtTriangle[] out_tris, IntPtr out_stats);
-        [DllImport(Lib)] public static extern int rt_camera_view_params(float fov_deg, float aspect, float focus_distance, [Out] float[] out3);
+        [DllImport(Lib)] public static extern int rt_camera_view_params(float fov_deg, float aspect, float focus_distance, out Float3 view_params);
+
+        // several GPUs from this one process (rt_abi.h: rt_create_multi): cyclic 8-row strips per device, gather at readback
+        [DllImport(Lib)] public static extern int rt_create_multi([In] int[] device_ids, int n_devices, out IntPtr multi);
+        [DllImport(Lib)] public static extern void rt_destroy_multi(IntPtr multi);
+        [DllImport(Lib)] public static extern IntPtr rt_multi_context(IntPtr multi, int i);
+        [DllImport(Lib)] public static extern int rt_multi_resize(IntPtr multi, int width, int height);
+        [DllImport(Lib)] public static extern int rt_multi_upload_scene(IntPtr multi,
+            [In] RtModel[] models, int n_models, [In] RtTriangle[] triangles, int n_triangles,
+            [In] RtBVHNode[] nodes, int n_nodes, [In] RtSphere[] spheres, int n_spheres);
+        [DllImport(Lib)] public static extern int rt_multi_update_models(IntPtr multi, [In] RtModel[] models, int n_models);
+        [DllImport(Lib)] public static extern int rt_multi_set_params(IntPtr multi, ref RtParams p);
+        [DllImport(Lib)] public static extern int rt_multi_reset_accumulation(IntPtr multi);
+        [DllImport(Lib)] public static extern int rt_multi_render_frame(IntPtr multi);
+        [DllImport(Lib)] public static extern int rt_multi_render_frames(IntPtr multi, int n);
+        [DllImport(Lib)] public static extern int rt_multi_synchronize(IntPtr multi);
+        [DllImport(Lib)] public static extern int rt_gather_accumulated(IntPtr multi, [Out] float[] rgba, UIntPtr bytes);
+        [DllImport(Lib)] public static extern int rt_multi_get_counters(IntPtr multi, out RtCounters c);
 
         public static void Check(IntPtr ctx, int status)
         {

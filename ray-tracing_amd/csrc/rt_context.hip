@@ -102,6 +102,8 @@ struct RtContext {
     Staging staging[8];
     int stagingNext = 0;
     uint64_t updateUploads = 0, updateSkips = 0; /* diagnostics: uploads enqueued / calls that changed nothing */
+    void* dDisplay = nullptr;  /* scratch of the display pass, kept between calls (grows on demand) */
+    size_t displayBytes = 0;
     hipEvent_t evStart = nullptr, evStop = nullptr;
     double gpuMs = 0;
     int timerState = 0; /* 0 idle, 1 begun, 2 ended (elapsed not yet read) */
@@ -270,6 +272,7 @@ void rt_destroy(RtContext* ctx)
     hipFree(ctx->dTileQueue);
     hipFree(ctx->dTileCost);
     hipFree(ctx->dTileOrder);
+    hipFree(ctx->dDisplay);
     for (RtContext::Staging& st : ctx->staging) {
         if (st.host) hipHostFree(st.host);
         if (st.done) hipEventDestroy(st.done);
@@ -1221,6 +1224,20 @@ static int display_common(RtContext* ctx, int frame, int use_accumulated, const 
     return RT_OK;
 }
 
+static int display_scratch(RtContext* ctx, size_t bytes, void** out)
+{
+    if (ctx->displayBytes < bytes) {
+        HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
+        hipFree(ctx->dDisplay);
+        ctx->dDisplay = nullptr;
+        ctx->displayBytes = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->dDisplay, bytes));
+        ctx->displayBytes = bytes;
+    }
+    *out = ctx->dDisplay;
+    return RT_OK;
+}
+
 int rt_display(RtContext* ctx, int frame, int use_accumulated, float* rgba, size_t bytes)
 {
     const float* src = nullptr;
@@ -1231,14 +1248,13 @@ int rt_display(RtContext* ctx, int frame, int use_accumulated, float* rgba, size
     if (n == 0) return RT_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     float4* tmp = nullptr;
-    HIP_TRY(ctx, hipMalloc(&tmp, bytes));
+    if ((rc = display_scratch(ctx, bytes, (void**)&tmp))) return rc;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(rtk::rt_display_kernel, dim3(blocks), dim3(256), 0, joined(ctx), (const float4*)src, tmp, n, frame);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(joined(ctx));
     if (e == hipSuccess) e = hipMemcpy(rgba, tmp, bytes, hipMemcpyDeviceToHost);
-    hipFree(tmp);
     if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_display: %s", hipGetErrorString(e));
     return RT_OK;
 }
@@ -1253,14 +1269,13 @@ int rt_display_srgb8(RtContext* ctx, int frame, int use_accumulated, int flip_y,
     if (n == 0) return RT_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     uint32_t* tmp = nullptr;
-    HIP_TRY(ctx, hipMalloc(&tmp, bytes));
+    if ((rc = display_scratch(ctx, bytes, (void**)&tmp))) return rc;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(rtk::rt_display_srgb8_kernel, dim3(blocks), dim3(256), 0, joined(ctx), (const float4*)src, tmp, ctx->W, ctx->localRows, frame, flip_y);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(joined(ctx));
     if (e == hipSuccess) e = hipMemcpy(rgba8, tmp, bytes, hipMemcpyDeviceToHost);
-    hipFree(tmp);
     if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_display_srgb8: %s", hipGetErrorString(e));
     return RT_OK;
 }

@@ -31,10 +31,26 @@ def cs_structs():
     out = {}
     for m in re.finditer(r"public struct (\w+)\s*\{(.*?)\n    \}", text, flags=re.S):
         fields = []
-        for fm in re.finditer(r"(?:\[MarshalAs\(UnmanagedType\.ByValArray, SizeConst = (\d+)\)\]\s*)?public (\w+)(\[\])? (\w+);", m.group(2)):
-            fields.append((fm.group(2), fm.group(4), int(fm.group(1) or 1)))
+        for fm in re.finditer(r"public (\w+) (\w+);", m.group(2)):
+            t, n = fm.group(1), fm.group(2)
+            # blittable vector types = that many consecutive floats of the C struct
+            fields.append(("float", n, VECTORS[t]) if t in VECTORS else (t, n, 1))
         out[m.group(1)] = fields
     return out
+
+
+VECTORS = {"Float3": 3, "Float4": 4, "Float4x4": 16}
+
+
+def test_csharp_structs_are_blittable():
+    """No reference-type fields (arrays, strings) and no MarshalAs: the runtime can pin RtModel[] etc. and pass the
+    memory as it is, like the reference's own RayTracingMaterial / MeshInfo (Color / Matrix4x4 fields)."""
+    text = open(os.path.join(ROOT, "host", "dotnet", "RayTraceNative.cs")).read()
+    body = text[:text.index("public static class RayTraceNative")]
+    assert "MarshalAs" not in body and "[]" not in re.sub(r"//.*", "", body)
+    for t, n in VECTORS.items():
+        m = re.search(r"public struct %s\b(.*?)\n    \}" % t, text, flags=re.S) or re.search(r"public struct %s \{(.*?)\}\s*\n" % t, text, flags=re.S)
+        assert m, t
 
 
 TYPE_MAP = {"float": "float", "int32_t": "int", "uint32_t": "uint", "uint64_t": "ulong", "double": "double",
