@@ -39,7 +39,22 @@ RT_HD float rt_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f;
 #define RT_INF (rt_u2f(0x7f800000u))
 
 /* ------------------------------------------------- exact single operations */
-RT_HD float rt_sqrt(float x) { return __builtin_sqrtf(x); } /* correctly rounded */
+RT_HD float rt_sqrt(float x) /* correctly rounded */
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_RCP_IEEE_SEQUENCE)
+    /* Same bits in 5 instructions instead of the compiler's 16: for 2^-95 <= x < 2^96, v_rsq_f32 (1 ulp), s = x r and
+     * one exact-residual correction s + (x - s s) r/2 give the correctly rounded square root — checked over all 2^32 bit
+     * patterns on gfx950 (tools/ubench/exact_math.hip: 0 mismatches in that range); zeros, negatives, tiny, huge, inf
+     * and NaN arguments take the IEEE sequence. */
+    if ((rt_f2u(x) >> 23) - 32u <= 190u) {
+        const float r = __builtin_amdgcn_rsqf(x);
+        const float s = x * r;
+        const float e = __builtin_fmaf(-s, s, x);
+        return __builtin_fmaf(e, 0.5f * r, s);
+    }
+#endif
+    return __builtin_sqrtf(x);
+}
 RT_HD float rt_abs(float x) { return rt_u2f(rt_f2u(x) & 0x7fffffffu); }
 RT_HD float rt_floor(float x) { return __builtin_floorf(x); } /* exact */
 
@@ -56,7 +71,37 @@ RT_HD float rt_lerp(float a, float b, float t) { return a + (b - a) * t; }
 /* HLSL '/': GPUs have no IEEE divide in shaders — a/b executes as a * rcp(b).  The strict
  * form used here keeps that shape with a correctly rounded reciprocal, so a reciprocal of
  * a wave-uniform or repeated denominator is computed once. */
-RT_HD float rt_rcp(float x) { return 1.0f / x; }
+RT_HD float rt_rcp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_RCP_IEEE_SEQUENCE)
+    /* Same bits, a third of the issue slots: on gfx950 v_rcp_f32 (1 ulp) followed by ONE fused Newton step is the
+     * correctly rounded reciprocal for every input whose biased exponent lies in [3, 251] (x and 1/x both normal) —
+     * checked over all 2^32 bit patterns against the compiler's 11-instruction IEEE sequence
+     * (tools/ubench/exact_math.hip: 0 mismatches in that range); everything else — zeros, subnormals, the last two
+     * binades, inf, NaN — takes the IEEE sequence. */
+    if (((rt_f2u(x) >> 23) & 0xffu) - 3u <= 248u) {
+        const float y = __builtin_amdgcn_rcpf(x);
+        const float e = __builtin_fmaf(-x, y, 1.0f);
+        return __builtin_fmaf(y, e, y);
+    }
+#endif
+    return 1.0f / x;
+}
+/* a / b, correctly rounded, for the two divisions inside rt_log and rt_exp.  On the device their operands are confined
+ * to ranges (b in [1.6, 2.5]) over which reciprocal + quotient + one exact-residual correction was checked to equal the
+ * IEEE quotient for EVERY argument the functions can produce (tools/ubench/exact_math.hip sweeps all 2^32 reduced
+ * arguments: 0 mismatches; the only differing input, f = -0 in rt_log, cannot arise from x - 1). */
+RT_HD float rt_div_narrow(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_RCP_IEEE_SEQUENCE)
+    float y = __builtin_amdgcn_rcpf(b);
+    y = __builtin_fmaf(y, __builtin_fmaf(-b, y, 1.0f), y);
+    const float q = a * y;
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), y, q);
+#else
+    return a / b;
+#endif
+}
 #ifndef RT_MATH_IEEE
 RT_HD float rt_div(float a, float b) { return a * rt_rcp(b); }
 #else
@@ -111,7 +156,7 @@ RT_HD float rt_log(float x)
     ix = (ix & 0x007fffffu) + 0x3f3504f3u;
     x = rt_u2f(ix);
     float f = x - 1.0f;
-    float s = f / (2.0f + f);
+    float s = rt_div_narrow(f, 2.0f + f);
     float z = s * s;
     float w = z * z;
     float t1 = w * (Lg2 + w * Lg4);
@@ -157,7 +202,7 @@ RT_HD float rt_exp(float x)
     }
     float xx = x * x;
     float c = x - xx * (P1 + xx * P2);
-    float y = 1.0f + (x * c / (2.0f - c) - lo + hi);
+    float y = 1.0f + (rt_div_narrow(x * c, 2.0f - c) - lo + hi);
     if (k == 0) return y;
     /* y * 2^k with a single rounding even when the result is subnormal */
     if (k > 127) { y *= 1.7014118346e38f; k -= 127; }          /* 2^127 */

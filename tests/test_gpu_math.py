@@ -46,3 +46,35 @@ def test_binary_bits(api, orc, op):
     nan = np.isnan(want)
     assert np.array_equal(np.isnan(got), nan)
     assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan]), op
+
+
+@pytest.mark.parametrize("op", ["rcp", "sqrt", "log", "exp", "div"])
+def test_fast_exact_sequences_equal_the_ieee_ones(api, orc, op):
+    """rt_rcp / rt_sqrt / the divisions inside rt_log and rt_exp run shorter instruction sequences on the device
+    (v_rcp_f32 / v_rsq_f32 + fused residual corrections, include/rt_math.h) that were proven bit-identical to the
+    correctly rounded results over all 2^32 inputs (tools/ubench/exact_math.hip).  Here: every binade x 4096
+    mantissas x both signs, the guard boundaries of the fast paths, and 3M random bit patterns, against the host
+    (which evaluates the plain IEEE forms)."""
+    rng = np.random.default_rng(77 + OPS[op])
+    ex = np.arange(0, 256, dtype=np.uint32)
+    man = np.concatenate([rng.integers(0, 1 << 23, 4090, dtype=np.uint64).astype(np.uint32), np.array([0, 1, 2, (1 << 23) - 1, (1 << 23) - 2, 1 << 22], dtype=np.uint32)])
+    grid = ((ex[:, None] << 23) | man[None, :]).reshape(-1)
+    bits = np.concatenate([grid, grid | np.uint32(0x80000000), rng.integers(0, 2 ** 32, 3_000_000, dtype=np.uint64).astype(np.uint32)])
+    x = bits.view(np.float32)
+    if op == "log":     # every reduced argument class: all mantissas of a few binades + the sweep above
+        x = np.concatenate([x, (np.uint32(0x3f000000) + np.arange(0, 1 << 24, 7, dtype=np.uint32)).view(np.float32)])
+    if op == "exp":
+        x = np.concatenate([x, rng.uniform(-104, 89, 2_000_000).astype(np.float32), rng.uniform(-0.36, 0.36, 2_000_000).astype(np.float32)])
+    tr = api.create_tracer(0)
+    if op == "div":
+        y = np.roll(x, 12345)
+        got = tr.debug_math_eval(OPS[op], x, y)
+        want = ev(orc, op, x, y)
+    else:
+        got = tr.debug_math_eval(OPS[op], x)
+        want = ev(orc, op, x)
+    tr.close()
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    bad = got.view(np.uint32)[~nan] != want.view(np.uint32)[~nan]
+    assert not bad.any(), (op, int(bad.sum()), x[~nan][bad][:5])

@@ -6,7 +6,7 @@ grep -A8 "Function Name: _ZN3rtk15rt_trace_kernelILb0ELb0" /root/repo/build/asm/
 python - <<'PY'
 import re
 s=open('/root/repo/build/asm/rt_context-hip-amdgcn-amd-amdhsa-gfx950.s').read()
-i=s.index('_ZN3rtk15rt_trace_kernelILb0ELb0EEEv5KArgs:')
+i=s.index('_ZN3rtk15rt_trace_kernelILb0ELb0ELb0EEEv5KArgs:')
 j=s.index('.Lfunc_end',i)
 body=s[i:j].split('\n')
 def stats(lines,name):

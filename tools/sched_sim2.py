@@ -491,7 +491,7 @@ if __name__ == "__main__":
         print(f"       -> x{b / k:.2f}")
 
 
-def sim_sorted(pixels, tiles_total, NW=4, every=4, sort_cost=45, burst=3, budget=0, timing=None):
+def sim_sorted(pixels, tiles_total, NW=4, every=4, sort_cost=45, burst=3, budget=0, timing=None, column_sort=False):
     """NW waves of one workgroup; every `every` iterations all rays of the workgroup are re-sorted by the
     phase they want next (state moved through LDS, `sort_cost` instructions per wave) and dealt out in
     runs of 64; between sorts each wave executes the phase most of its lanes want."""
@@ -536,7 +536,16 @@ def sim_sorted(pixels, tiles_total, NW=4, every=4, sort_cost=45, burst=3, budget
             break
         if every and it % every == 0:
             close_epoch()
-            lanes.sort(key=lambda c: (order + "Z").index(want(c)))
+            if column_sort:
+                # every lane column (the NW rays held by lane l of each wave) is sorted on its own: a ray never
+                # leaves its column, so its LDS-resident data stays bank-conflict free
+                for l in range(64):
+                    col = [lanes[w * 64 + l] for w in range(NW)]
+                    col.sort(key=lambda c: (order + "Z").index(want(c)))
+                    for w in range(NW):
+                        lanes[w * 64 + l] = col[w]
+            else:
+                lanes.sort(key=lambda c: (order + "Z").index(want(c)))
             acc.run("SORT", sum(1 for c in lanes if c.state != "D"), cost=sort_cost, mult=NW)
             for i in range(NW):
                 wcost[i] += sort_cost
