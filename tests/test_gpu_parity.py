@@ -309,6 +309,37 @@ def _strips_against_oracle(pkg, api, orc, cfg, strips):
         assert np.any(gpu[s * 8: s * 8 + 8, :, :3] > 0), (cfg, s)  # not a strip of black
 
 
+@pytest.mark.parametrize("cfg", [2, 3, 4, 5])
+def test_whole_full_size_frame_against_oracle(pkg, api, orc, cfg):
+    """Every pixel of one full-size frame of BASELINE configs 2-5 (1920x1080; config 5: 3840x2160, 983k triangles,
+    288 M path segments), not a sample of strips: bit for bit and with equal exact work counters.  The oracle needs the host's cores for this
+    (seconds on the many-core GPU boxes); on a small host the strip tests above and below stand in."""
+    cores = os.cpu_count() or 1
+    if cores < 32:
+        pytest.skip(f"{cores} host cores: the whole-frame oracle render would take minutes (strip tests cover this host)")
+    tr = api.create_tracer(0)
+    tr.enable_stats(True)
+    sc = pkg.scenes.get(cfg)
+    mgr = sc.make_manager(tr, api)
+    mgr.OnEnable(renderSeed=1)
+    mgr.RenderFrame()
+    gpu = tr.read_accumulated()
+    cg = tr.counters()
+    viol = tr.phase_profile()["filter_violations"][0]
+    tr.close()
+    c = orc.create_tracer(min(cores, 128))
+    m2 = pkg.scenes.get(cfg).make_manager(c, orc)
+    m2.OnEnable(renderSeed=1)
+    m2.RenderFrame()
+    cpu = c.read_accumulated()
+    cc = c.counters()
+    c.close()
+    assert gpu.shape == (sc.height, sc.width, 4) and sc.width >= 1920
+    assert bits_equal(gpu, cpu), int(np.sum(np.any(gpu.view(np.uint32) != cpu.view(np.uint32), axis=-1)))
+    assert [cg[k] for k in KEYS] == [cc[k] for k in KEYS]
+    assert viol == 0
+
+
 def test_config4_full_size_strip_sample(pkg, api, orc):
     """BASELINE config 4 as benchmarked: 1920x1080, depth of field on, the whole 81,920-triangle mesh."""
     sc = pkg.scenes.get(4)
