@@ -10,8 +10,11 @@ of the whole image (RayComputeManager.cs:84-95); successive steps are successive
 progressive render.  Scene and render targets are resident in HBM before the timed region.
 
 "rays" = path segments = CalculateRayCollision calls (RayCommon.hlsl:487), counted exactly by the kernel.
-`value` times K x rt_render_frame (the Dispatch only); `value_with_initframe` times K x the mirror's
-RenderFrame() = InitFrame (UpdateModels + SetShaderParams every frame, RCM:115-124) + Dispatch.
+`value` times K x rt_render_frame (the Dispatch only) issued back to back — the library holds frames requested
+while earlier ones still execute back (up to 16) and launches them fused, bit-identical to one launch per frame;
+`value_one_kernel_per_frame` is the same work at exactly one kernel per frame (the roofline pass);
+`value_with_initframe` times K x the mirror's RenderFrame() = InitFrame (UpdateModels + SetShaderParams every
+frame, RCM:115-124) + Dispatch.
 
 N > 1: one process per GPU.  With WORLD_SIZE unset, `python bench.py --gpus N` spawns the N ranks itself
 (torch.distributed.run, 127.0.0.1); under torch.distributed.run it is one rank.  The image is split into
@@ -140,6 +143,7 @@ def parity_check(pkg, api, dev_index, scene_id, width, height, strips):
 def pmc_child(args):
     """Child of the PMC passes: one kernel per frame on one stream, `steps` frames, nothing else (no torch)."""
     os.environ["RT_TWO_STREAMS"] = "0"
+    os.environ["RT_COALESCE"] = "0"
     pkg = graft.load_package()
     api = pkg.load_library()
     tr = api.create_tracer(0)
@@ -221,15 +225,17 @@ def replayed_pmc(config):
 
 def single_launch_ms(pkg, api, dev_index, scene_id, W, H, steps, warmup, partition=None):
     """Average duration of ONE kernel per frame on one stream (RT_TWO_STREAMS=0), HIP events on the launch stream."""
-    prev = os.environ.get("RT_TWO_STREAMS")
+    prev = {k: os.environ.get(k) for k in ("RT_TWO_STREAMS", "RT_COALESCE")}
     os.environ["RT_TWO_STREAMS"] = "0"
+    os.environ["RT_COALESCE"] = "0"
     try:
         t = api.create_tracer(dev_index)
     finally:
-        if prev is None:
-            del os.environ["RT_TWO_STREAMS"]
-        else:
-            os.environ["RT_TWO_STREAMS"] = prev
+        for k, v in prev.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     if partition:
         t.set_partition(*partition)
     sc = pkg.scenes.get(scene_id)
@@ -400,7 +406,7 @@ def main():
     # the figure rocprofv3 --kernel-trace reports for the same mode (profiles/).
     single_ms = None
     if rank == 0:
-        if os.environ.get("RT_TWO_STREAMS") == "0":
+        if os.environ.get("RT_TWO_STREAMS") == "0" and os.environ.get("RT_COALESCE") == "0":
             single_ms = timed["gpuMs"] / args.steps
         else:
             single_ms, seg1 = single_launch_ms(pkg, api, dev_index, args.config, W, H, args.steps, args.warmup,
@@ -475,8 +481,13 @@ def main():
             "value_with_initframe": total_segments / init_elapsed / 1e6,
             "ms_per_step_with_initframe": init_elapsed / args.steps * 1e3,
             "gather_ms": gather_ms,
-            "launches": "2 kernels per frame on 2 streams (disjoint tile halves, overlapping in time)"
-                        if os.environ.get("RT_TWO_STREAMS") != "0" else "1 kernel per frame",
+            "launches": ("K x rt_render_frame, back to back: the library starts an idle GPU at once (frame 1: 2 kernels on 2 streams, disjoint "
+                         "tile halves) and holds frames requested while earlier ones still execute back, up to 16, to launch them fused "
+                         "(each pixel runs its frames back to back; same bits); RT_COALESCE=0 = one launch per call")
+                        if os.environ.get("RT_COALESCE") != "0" else
+                        ("2 kernels per frame on 2 streams (disjoint tile halves, overlapping in time)"
+                         if os.environ.get("RT_TWO_STREAMS") != "0" else "1 kernel per frame"),
+            "value_one_kernel_per_frame": (segments / args.steps / (single_ms * 1e-3) / 1e6) if single_ms else None,
             "batched_api": batched,
             "parity": parity if parity is not None else "checked at N=1 (pytest -m gpu and the N=1 bench line)",
             "roofline": roof,

@@ -217,6 +217,14 @@ int rt_reset_accumulation(RtContext* ctx);
  * by rt_set_params), then increments the counter if accumulate (RCM:94).
  * Asynchronous: returns after enqueueing. */
 int rt_render_frame(RtContext* ctx);
+/* rt_render_frame only enqueues.  On the context's own stream, frames requested while earlier ones are still
+ * executing are held back (at most 16) and leave as ONE fused launch — the form of rt_render_frames below, same
+ * bits — as soon as 16 have gathered or at the next call that needs them: every call that changes what they
+ * depend on (params, models, spheres, targets, size), rt_reset_accumulation, and every call that hands results to the
+ * host (rt_synchronize, rt_read_x, rt_display_x, rt_get_counters, rt_timer_x).  An idle GPU is started at once.
+ * rt_flush launches the held frames without waiting (for hosts that go away for a while after the last
+ * rt_render_frame); RT_COALESCE=0 in the environment launches every frame at its call. */
+int rt_flush(RtContext* ctx);
 /* n consecutive frames Frame, Frame+1, ... : the same final FrameRender / AccumulatedRender
  * as n calls of rt_render_frame (same seeds, same per-pixel order of additions), but when
  * accumulating the frames are batched, up to 16 per launch, each pixel running its frames

@@ -92,6 +92,10 @@ struct RtContext {
     int occPerCU[6] = {0, 0, 0, 0, 0, 0};
     size_t occBytes[6] = {0, 0, 0, 0, 0, 0};
     bool verbose = false;
+    /* rt_render_frame calls that arrive while earlier frames are still executing are held back (at most
+     * RT_MAX_FUSED_FRAMES) and leave as ONE fused launch at the next call that needs them (flush_pending) */
+    bool coalesce = true;  /* RT_COALESCE=0: every rt_render_frame launches at once */
+    int pending = 0;       /* frames [frame - pending, frame) requested but not launched yet */
     bool fuseFrames = true; /* rt_render_frames(n): up to RT_MAX_FUSED_FRAMES frames per launch (RT_FUSE_FRAMES=0: one launch per frame) */
     int gridOverride = 0; /* test hook: force the persistent grid size */
     bool stats = false;
@@ -194,6 +198,24 @@ static int stage_upload(RtContext* ctx, void* dst, const void* src, size_t bytes
     return RT_OK;
 }
 
+static int launch_frames(RtContext* ctx, int frame0, int nFrames);
+
+/* Launch the frames rt_render_frame held back.  Called first thing by every entry point that reads or changes
+ * what those frames depend on, or that hands results to the host. */
+static int flush_pending(RtContext* ctx)
+{
+    if (!ctx || ctx->pending == 0) return RT_OK;
+    const int n = ctx->pending;
+    ctx->pending = 0;
+    hipSetDevice(ctx->device);
+    return launch_frames(ctx, ctx->frame - n, n);
+}
+#define RT_FLUSH(ctx)                         \
+    do {                                      \
+        int frc_ = flush_pending(ctx);        \
+        if (frc_ != RT_OK) return frc_;       \
+    } while (0)
+
 extern "C" {
 
 const char* rt_version(void) { return RT_VERSION_STRING; }
@@ -240,6 +262,7 @@ int rt_create(int device_id, RtContext** out)
     if (const char* f = getenv("RT_FUSE_FRAMES")) ctx->fuseFrames = atoi(f) != 0;
     if (const char* l = getenv("RT_LPT")) ctx->lptEnabled = atoi(l) != 0;
     if (const char* t = getenv("RT_TWO_STREAMS")) ctx->twoStreams = atoi(t) != 0;
+    if (const char* c = getenv("RT_COALESCE")) ctx->coalesce = atoi(c) != 0;
     *out = ctx;
     return RT_OK;
 }
@@ -263,6 +286,7 @@ void rt_destroy(RtContext* ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    flush_pending(ctx);
     if (ctx->sideStream) hipStreamSynchronize(ctx->sideStream);
     hipStreamSynchronize(ctx->stream);
     free_scene(ctx);
@@ -289,6 +313,7 @@ void rt_destroy(RtContext* ctx)
 int rt_set_stream(RtContext* ctx, void* hip_stream)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
     hipStreamSynchronize(joined(ctx));
     flush_timer(ctx);
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->ownStream;
@@ -298,6 +323,7 @@ int rt_set_stream(RtContext* ctx, void* hip_stream)
 int rt_set_partition(RtContext* ctx, int strip_rows, int part_index, int part_count)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
     if (strip_rows <= 0 || strip_rows % 8 || part_count <= 0 || part_index < 0 || part_index >= part_count)
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_set_partition: strip_rows must be a positive multiple of 8, 0 <= index < count");
     ctx->stripRows = strip_rows;
@@ -310,6 +336,7 @@ int rt_set_partition(RtContext* ctx, int strip_rows, int part_index, int part_co
 int rt_resize(RtContext* ctx, int width, int height)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
     if (width <= 0 || height <= 0) return fail(ctx, RT_ERR_INVALID_ARG, "rt_resize: %dx%d", width, height);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
@@ -348,6 +375,7 @@ int rt_local_to_global_row(const RtContext* ctx, int local_row)
 int rt_bind_render_targets(RtContext* ctx, void* d_frame, void* d_accum)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
     if (((uintptr_t)d_frame | (uintptr_t)d_accum) & 15) return fail(ctx, RT_ERR_INVALID_ARG, "render targets must be 16-byte aligned");
     HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
     ctx->boundFrame = (float*)d_frame;
@@ -741,6 +769,7 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
                     const RtBVHNode* nodes, int n_nodes, const RtSphere* spheres, int n_spheres)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
     if (n_models < 0 || n_triangles < 0 || n_nodes < 0 || n_spheres < 0 || (n_models && !models) || (n_triangles && !triangles) ||
         (n_nodes && !nodes) || (n_spheres && !spheres))
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_scene: bad pointer/count");
@@ -872,6 +901,7 @@ int rt_update_models(RtContext* ctx, const RtModel* models, int n_models)
         ctx->updateSkips++;
         return RT_OK;
     }
+    RT_FLUSH(ctx); /* frames held back were requested with the old models */
     std::vector<DModel> dmodels(n_models);
     std::vector<DMaterial> mats(n_models);
     bool matricesChanged = false;
@@ -909,6 +939,7 @@ int rt_update_spheres(RtContext* ctx, const RtSphere* spheres, int n_spheres)
         ctx->updateSkips++;
         return RT_OK;
     }
+    RT_FLUSH(ctx);
     std::vector<float> sph;
     pack_spheres(spheres, n_spheres, sph, &ctx->sphereBound);
     std::vector<DMaterial> mats(n_spheres);
@@ -934,6 +965,12 @@ int rt_set_params(RtContext* ctx, const RtParams* p)
     if (p->abi_version != RT_ABI_VERSION || p->struct_size != sizeof(RtParams))
         return fail(ctx, RT_ERR_ABI_MISMATCH, "rt_set_params: abi_version %u / struct_size %u, library has %u / %zu", p->abi_version,
                     p->struct_size, (unsigned)RT_ABI_VERSION, sizeof(RtParams));
+    if (ctx->haveParams && p->frame == ctx->frame) { /* SetShaderParams runs every frame (RCM:122): usually nothing but Frame moved, and it moved to where the context already is */
+        RtParams a = *p, b = ctx->params;
+        a.frame = b.frame = 0;
+        if (memcmp(&a, &b, sizeof(RtParams)) == 0) return RT_OK;
+    }
+    RT_FLUSH(ctx);
     ctx->params = *p;
     ctx->frame = p->frame;
     ctx->haveParams = true;
@@ -943,6 +980,7 @@ int rt_set_params(RtContext* ctx, const RtParams* p)
 int rt_reset_accumulation(RtContext* ctx)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
     if (ctx->W == 0) return fail(ctx, RT_ERR_STATE, "rt_reset_accumulation before rt_resize");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     float* accum = ctx->boundAccum ? ctx->boundAccum : ctx->ownAccum;
@@ -1125,14 +1163,46 @@ static int check_renderable(RtContext* ctx)
     return RT_OK;
 }
 
+static bool gpu_idle(RtContext* ctx)
+{
+    if (hipStreamQuery(ctx->stream) != hipSuccess) return false;
+    if (ctx->sideStream && ctx->sideDirty && hipStreamQuery(ctx->sideStream) != hipSuccess) return false;
+    return true;
+}
+
 int rt_render_frame(RtContext* ctx)
 {
     int rc = check_renderable(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    /* Frames requested while earlier ones still execute are held back and leave as one fused launch (each pixel
+     * runs its frames back to back: same bits as one launch per frame, without a chip-wide drain per frame) when
+     * RT_MAX_FUSED_FRAMES have gathered or at the next call that needs them.  An idle GPU starts at once. */
+    if (ctx->coalesce && ctx->fuseFrames && ctx->params.accumulate && ctx->stream == ctx->ownStream) {
+        if (gpu_idle(ctx)) {
+            RT_FLUSH(ctx);
+            rc = launch_frames(ctx, ctx->frame, 1);
+            if (rc) return rc;
+            ctx->frame++;
+            return RT_OK;
+        }
+        ctx->pending++;
+        ctx->frame++; /* RCM:94 */
+        if (ctx->pending >= RT_MAX_FUSED_FRAMES) RT_FLUSH(ctx);
+        return RT_OK;
+    }
+    RT_FLUSH(ctx);
     rc = launch_frames(ctx, ctx->frame, 1);
     if (rc) return rc;
     if (ctx->params.accumulate) ctx->frame++; /* RCM:94 */
+    return RT_OK;
+}
+
+/* Launch what rt_render_frame holds back, without waiting for it. */
+int rt_flush(RtContext* ctx)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
     return RT_OK;
 }
 
@@ -1142,6 +1212,7 @@ int rt_render_frames(RtContext* ctx, int n)
     if (rc) return rc;
     if (n < 0) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render_frames: n < 0");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RT_FLUSH(ctx);
     if (ctx->fuseFrames && ctx->params.accumulate) {
         /* Batched form: each pixel runs its frames back to back inside one launch — same Frame
          * seeds, same order of additions into the sum, FrameRender = the last frame — so the
@@ -1167,6 +1238,7 @@ int rt_render_frames(RtContext* ctx, int n)
 int rt_synchronize(RtContext* ctx)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
     flush_timer(ctx);
     return RT_OK;
@@ -1177,6 +1249,7 @@ int rt_get_frame(const RtContext* ctx) { return ctx ? ctx->frame : RT_ERR_INVALI
 int rt_timer_begin(RtContext* ctx)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
     flush_timer(ctx);
     if (ctx->timerState == 1) return fail(ctx, RT_ERR_STATE, "rt_timer_begin: timer already running");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1187,6 +1260,7 @@ int rt_timer_begin(RtContext* ctx)
 int rt_timer_end(RtContext* ctx)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
     if (ctx->timerState != 1) return fail(ctx, RT_ERR_STATE, "rt_timer_end without rt_timer_begin");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipEventRecord(ctx->evStop, joined(ctx)));
@@ -1197,6 +1271,7 @@ int rt_timer_end(RtContext* ctx)
 static int read_target(RtContext* ctx, const float* src, float* rgba, size_t bytes)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
     size_t want = (size_t)ctx->localRows * ctx->W * 16;
     if (!rgba || bytes != want) return fail(ctx, RT_ERR_INVALID_ARG, "read: need exactly %zu bytes, got %zu", want, bytes);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1218,6 +1293,7 @@ int rt_read_accumulated(RtContext* ctx, float* rgba, size_t bytes)
 static int display_common(RtContext* ctx, int frame, int use_accumulated, const float** src)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
     if (ctx->W == 0) return fail(ctx, RT_ERR_STATE, "display before rt_resize");
     if (frame == 0) return fail(ctx, RT_ERR_INVALID_ARG, "display: Frame must not be 0");
     *src = use_accumulated ? (ctx->boundAccum ? ctx->boundAccum : ctx->ownAccum) : (ctx->boundFrame ? ctx->boundFrame : ctx->ownFrame);
@@ -1283,6 +1359,7 @@ int rt_display_srgb8(RtContext* ctx, int frame, int use_accumulated, int flip_y,
 int rt_write_accumulated(RtContext* ctx, const float* rgba, size_t bytes)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
     const size_t want = (size_t)ctx->localRows * ctx->W * 16;
     if (!rgba || bytes != want) return fail(ctx, RT_ERR_INVALID_ARG, "rt_write_accumulated: need exactly %zu bytes, got %zu", want, bytes);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1294,6 +1371,7 @@ int rt_write_accumulated(RtContext* ctx, const float* rgba, size_t bytes)
 int rt_enable_stats(RtContext* ctx, int enabled)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
     ctx->stats = enabled != 0;
     return RT_OK;
 }
@@ -1301,6 +1379,7 @@ int rt_enable_stats(RtContext* ctx, int enabled)
 int rt_reset_counters(RtContext* ctx)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
     flush_timer(ctx);
@@ -1313,6 +1392,7 @@ int rt_reset_counters(RtContext* ctx)
 int rt_get_counters(RtContext* ctx, RtCounters* out)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
     if (!out) return fail(ctx, RT_ERR_INVALID_ARG, "rt_get_counters: null out");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
@@ -1341,6 +1421,7 @@ int rt_get_counters(RtContext* ctx, RtCounters* out)
 int rt_debug_phase_profile(RtContext* ctx, uint64_t* out, int n)
 {
     if (!ctx || !out || n < 2 * RT_N_PHASES) return fail(ctx, RT_ERR_INVALID_ARG, "rt_debug_phase_profile: need %d entries", 2 * RT_N_PHASES);
+    RT_FLUSH(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
     std::vector<unsigned long long> h((size_t)RT_COUNTER_SLOTS * RT_COUNTER_FIELDS);
@@ -1366,6 +1447,7 @@ struct DevScratch {
 
 int rt_debug_intersect(RtContext* ctx, const float* origins, const float* dirs, int n, float* out10)
 {
+    if (ctx) RT_FLUSH(ctx);
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     if (!ctx->haveScene) return fail(ctx, RT_ERR_STATE, "rt_debug_intersect before rt_upload_scene");
     if (n < 0 || (n && (!origins || !dirs || !out10))) return fail(ctx, RT_ERR_INVALID_ARG, "rt_debug_intersect: bad arguments");
@@ -1388,6 +1470,7 @@ int rt_debug_intersect(RtContext* ctx, const float* origins, const float* dirs, 
 
 int rt_debug_math_eval(RtContext* ctx, int op, const float* x, const float* y, float* out, int n)
 {
+    if (ctx) RT_FLUSH(ctx);
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     if (n < 0 || (n && (!x || !y || !out))) return fail(ctx, RT_ERR_INVALID_ARG, "rt_debug_math_eval: bad arguments");
     if (n == 0) return RT_OK;

@@ -22,6 +22,7 @@ ABI_SYMBOLS = [
     "rt_write_accumulated", "rt_timer_begin", "rt_timer_end",
     "rt_enable_stats", "rt_reset_counters", "rt_get_counters", "rt_build_bvh", "rt_build_bvh_mt", "rt_camera_view_params", "rt_version",
     "rt_debug_intersect", "rt_debug_math_eval", "rt_debug_phase_profile",
+    "rt_flush",
     "rt_create_multi", "rt_destroy_multi", "rt_multi_count", "rt_multi_context", "rt_multi_resize", "rt_multi_upload_scene",
     "rt_multi_update_models", "rt_multi_update_spheres", "rt_multi_set_params", "rt_multi_reset_accumulation",
     "rt_multi_render_frame", "rt_multi_render_frames", "rt_multi_synchronize", "rt_gather_accumulated", "rt_gather_frame",
@@ -39,6 +40,7 @@ class HipApi(abi.CApi):
         "bind_render_targets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
         "get_render_targets": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
         "synchronize": (C.c_int, [C.c_void_p]),
+        "flush": (C.c_int, [C.c_void_p]),
         "timer_begin": (C.c_int, [C.c_void_p]),
         "timer_end": (C.c_int, [C.c_void_p]),
         "enable_stats": (C.c_int, [C.c_void_p, C.c_int]),
@@ -216,6 +218,9 @@ class HipTracer(abi.Tracer):
 
     def synchronize(self):
         self._check(self.api.synchronize(self.h))
+
+    def flush(self):
+        self._check(self.api.flush(self.h))
 
     def timer_begin(self):
         self._check(self.api.timer_begin(self.h))

@@ -382,6 +382,41 @@ def test_persistent_grid_size_does_not_change_results(pkg, api, orc, grid, monke
     assert [ca[k] for k in KEYS] == [cb[k] for k in KEYS]
 
 
+@pytest.mark.parametrize("coalesce", ["0", "1"])
+def test_held_back_frames_see_the_state_they_were_requested_with(pkg, api, orc, coalesce, monkeypatch):
+    """rt_render_frame holds frames requested while the GPU is busy back and launches them fused.  Every call that
+    changes what they depend on must flush them first: here the bounce limit, a model matrix and the sphere set
+    change between bursts of back-to-back frames; the oracle renders the same sequence frame by frame."""
+    monkeypatch.setenv("RT_COALESCE", coalesce)
+    out = []
+    for lib in (api, orc):
+        tr = lib.create_tracer(0 if lib is api else 8)
+        sc = pkg.scenes.get(3)
+        sc.spheres = [pkg.Sphere((0.3, 0.6, 0.2), 0.25, pkg.RayTracingMaterial(diffuseCol=(0.9, 0.5, 0.2, 1)))]
+        mgr = sc.make_manager(tr, lib, 120, 72)
+        mgr.OnEnable(renderSeed=9)
+        frames_seen = []
+        for burst in range(4):
+            for _ in range(7):
+                mgr.RenderFrame()          # InitFrame (UpdateModels + SetShaderParams) + dispatch, back to back
+            frames_seen.append(tr.frame())
+            if burst == 0:
+                mgr.maxBounceCount = 3
+            elif burst == 1:
+                t = mgr.models[2].transform
+                t.position = (t.position[0] + 0.2, t.position[1], t.position[2])
+            elif burst == 2:
+                mgr.spheres[0].centre = (0.1, 0.7, 0.2)
+                tr.update_spheres(mgr._pack_spheres())
+        if lib is api:
+            tr.flush()                     # launches what is held back without waiting
+        assert frames_seen == [8, 15, 22, 29]
+        out.append((tr.read_accumulated().copy(), tr.read_frame().copy(), tr.counters()["segments"]))
+        tr.close()
+    (a, fa, sa), (b, fb, sb) = out
+    assert bits_equal(a, b) and bits_equal(fa, fb) and sa == sb
+
+
 @pytest.mark.parametrize("two", ["0", "1"])
 def test_one_or_two_render_streams_same_bits(pkg, api, orc, two, monkeypatch):
     """Default: every frame is two kernels over disjoint tile halves on two streams (joined lazily at
