@@ -415,13 +415,22 @@ def main():
 
     # ---- readback: the one collective of the multi-GPU path
     gather_ms = None
+    gather_error = None
+    gather_alpha_ok = None
     if tiled:
         barrier()
         g0 = time.perf_counter()
-        full = tiled.gather_accumulated(H, comm_device=comm_device)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        del full
+        try:
+            full = tiled.gather_accumulated(H, comm_device=comm_device)
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - g0) * 1e3
+            if rank == 0:
+                assert tuple(full.shape) == (H, W, 4)
+                gather_alpha_ok = bool((full[..., 3] == float(tracer.frame() - 1)).all().item())  # every pixel accumulated every frame
+            del full
+        except Exception as e:  # the timed result stands on its own; report the collective's failure instead of losing the line
+            gather_ms = None
+            gather_error = f"{type(e).__name__}: {e}"
 
     if world > 1:
         t = torch.tensor([elapsed, float(timed["gpuMs"]), init_elapsed], dtype=torch.float64, device=comm_device)
@@ -480,7 +489,7 @@ def main():
             "kernel_ms_per_step": kernel_ms_max / args.steps,
             "value_with_initframe": total_segments / init_elapsed / 1e6,
             "ms_per_step_with_initframe": init_elapsed / args.steps * 1e3,
-            "gather_ms": gather_ms,
+            "gather_ms": gather_ms, "gather_error": gather_error, "gathered_image_complete": gather_alpha_ok,
             "launches": ("K x rt_render_frame, back to back: the library starts an idle GPU at once (frame 1: 2 kernels on 2 streams, disjoint "
                          "tile halves) and holds frames requested while earlier ones still execute back, up to 16, to launch them fused "
                          "(each pixel runs its frames back to back; same bits); RT_COALESCE=0 = one launch per call")

@@ -735,6 +735,14 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
         const RT_CAS KArgs& c = cold_args();
         int tile = (int)blockIdx.x;
         if (tile < c.launchTiles && c.nFrames > 0 && !c.queueStart) {
+#ifdef RT_TILE_PRIORITY
+            if (c.tileOrder) {
+                const int T = c.launchTiles;
+                if (tile < (T >> 4)) __builtin_amdgcn_s_setprio(3);
+                else if (tile < (T >> 2)) __builtin_amdgcn_s_setprio(2);
+                else if (tile < (T >> 1)) __builtin_amdgcn_s_setprio(1);
+            }
+#endif
             tile = tile * c.orderStride + c.orderOffset;
             if (c.tileOrder) tile = (int)c.tileOrder[tile];
             RT_SET_POOL(c, tile);
@@ -779,6 +787,19 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                 if (lane == 0) next = (int)(atomicAdd(c.tileQueue, 1ull) - c.tileQueueBase);
                 next = __builtin_amdgcn_readfirstlane(next);
                 if (next >= c.launchTiles) { queueEmpty = true; break; }
+#ifdef RT_TILE_PRIORITY
+                /* EXPERIMENT (-DRT_TILE_PRIORITY; measured within +-3 % of the shipped kernel on configs 2/3/5, whole
+                 * image and 1/8 partitions, so not enabled): a launch cannot end before its longest pixel chains do, and a chain advances one
+                 * iteration per turn its wave gets on the SIMD.  With the learnt longest-chain-first order the queue
+                 * position says how long the tile's chains are: waves working on the longest ones get issue priority. */
+                if (c.tileOrder) {
+                    const int q = next, T = c.launchTiles;
+                    if (q < (T >> 4)) __builtin_amdgcn_s_setprio(3);
+                    else if (q < (T >> 2)) __builtin_amdgcn_s_setprio(2);
+                    else if (q < (T >> 1)) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+#endif
                 next = next * c.orderStride + c.orderOffset;
                 if (c.tileOrder) next = (int)c.tileOrder[next];
                 RT_SET_POOL(c, next);
