@@ -319,6 +319,14 @@ int rt_build_bvh_mt(const float* verts, const float* normals, int n_verts,
                     const int32_t* indices, int n_indices, int quality, int n_threads,
                     RtBVHNode* out_nodes, int* out_n_nodes,
                     RtTriangle* out_tris, RtBvhStats* out_stats);
+/* The same builder on the GPU `device_id` (host pointers in and out, like rt_build_bvh): level-synchronous,
+ * byte-identical output — ordered chunk reductions for the sweeps, prefix sum + pointer jumping for the reference's
+ * in-place partition, pre-order numbering for its node allocation order (ray-tracing_amd/csrc/rt_bvh_gpu.hip).
+ * RT_ERR_NO_DEVICE without a HIP device. */
+int rt_build_bvh_gpu(int device_id, const float* verts, const float* normals, int n_verts,
+                     const int32_t* indices, int n_indices, int quality,
+                     RtBVHNode* out_nodes, int* out_n_nodes,
+                     RtTriangle* out_tris, RtBvhStats* out_stats);
 /* RCM:183-190 UpdateCameraParams: fills viewParams from (fovDeg, aspect, focusDist). */
 int rt_camera_view_params(float fov_deg, float aspect, float focus_distance, float out_view_params[3]);
 

@@ -1,0 +1,693 @@
+/*
+ * rt_bvh_gpu.hip — rt_build_bvh_gpu: the reference's BVH constructor (Assets/Scripts/Types/BVH.cs:26-318)
+ * on the GPU, byte-identical to rt_build_bvh (same nodes, same triangle order, same statistics).
+ *
+ * BVH.cs is a depth-first recursion whose three ingredients look sequential; none of them is:
+ *   - EvaluateSplit (BVH:253-311) scans a node's triangles keeping running min/max with "if (t < cur) cur = t":
+ *     the first of equal values stays (signed zeros).  Any ORDERED reduction of ordered chunks gives the same
+ *     bits: here 128-triangle runs reduced sequentially by one thread per candidate plane, four runs per
+ *     512-triangle chunk, chunks combined in order;
+ *   - the in-place partition (BVH:117-153) is a Lomuto scan: a triangle that goes left is swapped with the FIRST
+ *     triangle of the right-hand block, which thereby moves to the back of that block — a rotating queue.  Number
+ *     the scan's events from the first right-hand triangle on: event p writes "tape" position p; a right-hand
+ *     triangle writes itself, the r-th left-hand triangle writes a copy of tape position r; the final right-hand
+ *     block is the last nRight tape positions, the left-hand block is stable.  That is one prefix sum of the
+ *     left flags plus a pointer-jumping pass over tape[p] -> tape[r(p)] (r(p) < p);
+ *   - node indices are handed out in depth-first order at split time (BVH:161-162): the children of the k-th
+ *     inner node in PRE-order get indices 1+2k, 2+2k.  The tree is built level by level into a breadth-first
+ *     array; subtree inner-node counts (bottom-up) and pre-order ranks (top-down) give every node its index.
+ * The arithmetic (candidate planes, costs, strict comparisons, the (axis 0, pos 0) fallback) is the host builder's,
+ * compiled with the same flags (no contraction, correctly rounded divide).
+ */
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <thread>
+#include <vector>
+
+#include "../../include/rt_abi.h"
+
+namespace gbvh {
+
+#define GB_FMAX 3.40282347e+38f
+#define GB_CHUNK 512          /* triangles per sweep chunk */
+#define GB_RUN 128            /* triangles per sequential run inside a chunk */
+#define GB_NCAND 16           /* 15 candidate planes (BVH:211-246) + the (axis 0, pos 0) fallback split */
+
+struct GTri {
+    float c[3], mn[3], mx[3];
+    int index;
+};
+struct GBox {
+    float lmn[3], lmx[3], rmn[3], rmx[3];
+    int nLeft;
+};
+struct GCand {
+    int axis;
+    float pos;
+};
+struct GNode { /* breadth-first record */
+    float bmin[3], bmax[3];
+    int start, count, depth;
+    int left;        /* breadth-first index of the left child (right = left + 1); -1: leaf or undecided */
+    int innerCount;  /* inner nodes in this subtree */
+    int preIdx;      /* pre-order rank among inner nodes */
+    int id;          /* final node index */
+    int nCand;       /* candidates of this level's sweep */
+    int chunkBase;   /* first sweep chunk */
+    int splitAxis;
+    float splitPos;
+    int nLeft;
+};
+
+__device__ __forceinline__ float max3f(float a, float b, float c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+
+__device__ __forceinline__ void box_reset(GBox& b)
+{
+    for (int k = 0; k < 3; k++) { b.lmn[k] = GB_FMAX; b.lmx[k] = -GB_FMAX; b.rmn[k] = GB_FMAX; b.rmx[k] = -GB_FMAX; }
+    b.nLeft = 0;
+}
+/* append the box of a LATER run: the earlier one keeps equal values */
+__device__ __forceinline__ void box_append(GBox& a, const GBox& o)
+{
+    for (int k = 0; k < 3; k++) {
+        if (o.lmn[k] < a.lmn[k]) a.lmn[k] = o.lmn[k];
+        if (o.lmx[k] > a.lmx[k]) a.lmx[k] = o.lmx[k];
+        if (o.rmn[k] < a.rmn[k]) a.rmn[k] = o.rmn[k];
+        if (o.rmx[k] > a.rmx[k]) a.rmx[k] = o.rmx[k];
+    }
+    a.nLeft += o.nLeft;
+}
+
+/* BVH:44-52 */
+__global__ void k_prepare(const float* verts, const int* indices, int ntri, GTri* tris, int* triNode)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntri) return;
+    const float* a = verts + 3 * indices[3 * t + 0];
+    const float* b = verts + 3 * indices[3 * t + 1];
+    const float* c = verts + 3 * indices[3 * t + 2];
+    GTri g;
+    for (int k = 0; k < 3; k++) {
+        g.c[k] = (a[k] + b[k] + c[k]) / 3;
+        g.mn[k] = a[k] < b[k] ? (a[k] < c[k] ? a[k] : c[k]) : (b[k] < c[k] ? b[k] : c[k]);
+        g.mx[k] = a[k] > b[k] ? (a[k] > c[k] ? a[k] : c[k]) : (b[k] > c[k] ? b[k] : c[k]);
+    }
+    g.index = 3 * t;
+    tris[t] = g;
+    triNode[t] = 0;
+}
+
+/* ChooseSplit's candidate planes (BVH:183-250), in evaluation order; slot 15 = the (0, 0) fallback */
+__global__ void k_candidates(GNode* nodes, int first, int nActive, int quality, GCand* cands)
+{
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nActive) return;
+    GNode& n = nodes[first + a];
+    GCand* cd = cands + (size_t)a * GB_NCAND;
+    for (int j = 0; j < GB_NCAND; j++) { cd[j].axis = 0; cd[j].pos = 0.0f; }
+    int nc = 0;
+    if (n.count > 1) { /* BVH:185 */
+        const float size[3] = {n.bmax[0] - n.bmin[0], n.bmax[1] - n.bmin[1], n.bmax[2] - n.bmin[2]};
+        if (quality == RT_BVH_QUALITY_LOW) {
+            int ax = (size[0] > size[1] && size[0] > size[2]) ? 0 : (size[1] > size[2] ? 1 : 2);
+            cd[0].axis = ax;
+            cd[0].pos = n.bmin[ax] + size[ax] * 0.5f;
+            nc = 1;
+        } else {
+            const int maxSplitTests = n.count < 10 ? 3 : 5;
+            const float maxAxis = max3f(size[0], size[1], size[2]);
+            for (int axis = 0; axis < 3; axis++) {
+                float v = size[axis] / maxAxis * maxSplitTests;
+                int m = (v != v) ? INT32_MIN : (int)ceilf(v); /* CeilToInt(NaN) == int.MinValue */
+                m = m < 1 ? 1 : (m > maxSplitTests ? maxSplitTests : m);
+                for (int i = 0; i < m; i++) {
+                    float splitT = (i + 1) / (m + 1.0f);
+                    cd[nc].axis = axis;
+                    cd[nc].pos = n.bmin[axis] + size[axis] * splitT;
+                    nc++;
+                }
+            }
+        }
+    }
+    n.nCand = nc;
+}
+
+__global__ void k_chunk_counts(const GNode* nodes, int first, int nActive, int* counts)
+{
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nActive) return;
+    const GNode& n = nodes[first + a];
+    counts[a] = n.nCand > 0 ? (n.count + GB_CHUNK - 1) / GB_CHUNK : 0;
+}
+__global__ void k_chunk_map(GNode* nodes, int first, int nActive, const int* chunkBase, const int* counts, int* chunkNode)
+{
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nActive) return;
+    nodes[first + a].chunkBase = chunkBase[a];
+    for (int k = 0; k < counts[a]; k++) chunkNode[chunkBase[a] + k] = a;
+}
+
+/* EvaluateSplit (BVH:253-311) over one chunk of one node: thread (candidate j, run s) scans its run of up to
+ * GB_RUN triangles sequentially with the reference's strict comparisons; the four runs are appended in order. */
+__global__ void __launch_bounds__(64) k_sweep(const GNode* nodes, int first, const int* chunkNode, const int* nChunksPtr, const GCand* cands, const GTri* tris,
+                                              GBox* partial)
+{
+    __shared__ float s_c[3][GB_CHUNK];
+    __shared__ float s_mn[3][GB_CHUNK];
+    __shared__ float s_mx[3][GB_CHUNK];
+    __shared__ GBox s_run[4][GB_NCAND];
+    const int chunk = blockIdx.x;
+    if (chunk >= *nChunksPtr) return; /* the grid is an upper bound (no read-back of the chunk count) */
+    const int a = chunkNode[chunk];
+    const GNode& n = nodes[first + a];
+    const int begin = n.start + (chunk - n.chunkBase) * GB_CHUNK;
+    const int end = (begin + GB_CHUNK < n.start + n.count) ? begin + GB_CHUNK : n.start + n.count;
+    const int m = end - begin;
+    for (int i = threadIdx.x; i < m; i += 64) {
+        const GTri t = tris[begin + i];
+        for (int k = 0; k < 3; k++) { s_c[k][i] = t.c[k]; s_mn[k][i] = t.mn[k]; s_mx[k][i] = t.mx[k]; }
+    }
+    __syncthreads();
+    const int j = threadIdx.x & 15, s = threadIdx.x >> 4;
+    const int nc = n.nCand;
+    const bool work = (j < nc) || (j == GB_NCAND - 1);
+    GBox b;
+    box_reset(b);
+    if (work) {
+        const GCand cd = cands[(size_t)a * GB_NCAND + j];
+        const int r0 = s * GB_RUN, r1 = (r0 + GB_RUN < m) ? r0 + GB_RUN : m;
+        for (int i = r0; i < r1; i++) {
+            if (s_c[cd.axis][i] < cd.pos) {
+                for (int k = 0; k < 3; k++) {
+                    if (s_mn[k][i] < b.lmn[k]) b.lmn[k] = s_mn[k][i];
+                    if (s_mx[k][i] > b.lmx[k]) b.lmx[k] = s_mx[k][i];
+                }
+                b.nLeft++;
+            } else {
+                for (int k = 0; k < 3; k++) {
+                    if (s_mn[k][i] < b.rmn[k]) b.rmn[k] = s_mn[k][i];
+                    if (s_mx[k][i] > b.rmx[k]) b.rmx[k] = s_mx[k][i];
+                }
+            }
+        }
+    }
+    s_run[s][j] = b;
+    __syncthreads();
+    if (s == 0 && work) {
+        GBox acc = s_run[0][j];
+        for (int r = 1; r < 4; r++) box_append(acc, s_run[r][j]);
+        partial[(size_t)chunk * GB_NCAND + j] = acc;
+    }
+}
+
+__device__ __forceinline__ float node_cost(const float* mn, const float* mx, int n) /* BVH:313-318 */
+{
+    if (n == 0) return 0;
+    float x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
+    float area = x * y + x * z + y * z;
+    return area * n;
+}
+
+/* per active node: combine the chunk partials in order, choose the split (BVH:200-208), decide (BVH:101) */
+__global__ void k_choose(GNode* nodes, int first, int nActive, int quality, const GCand* cands, const GBox* partial, const int* chunkCounts,
+                         GBox* chosen, int* splitFlag)
+{
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nActive) return;
+    GNode& n = nodes[first + a];
+    const int nc = n.nCand;
+    int best = -1;
+    float cost = INFINITY; /* count <= 1: BVH:185 */
+    GBox bestBox, fallback;
+    box_reset(bestBox);
+    box_reset(fallback);
+    if (nc > 0) {
+        float bestCost = GB_FMAX;
+        const int nChunks = chunkCounts[a];
+        for (int j = 0; j < GB_NCAND; j++) {
+            if (j >= nc && j != GB_NCAND - 1) continue;
+            GBox acc = partial[(size_t)n.chunkBase * GB_NCAND + j];
+            for (int c = 1; c < nChunks; c++) box_append(acc, partial[(size_t)(n.chunkBase + c) * GB_NCAND + j]);
+            if (j == GB_NCAND - 1) { fallback = acc; continue; }
+            float cj = node_cost(acc.lmn, acc.lmx, acc.nLeft) + node_cost(acc.rmn, acc.rmx, n.count - acc.nLeft);
+            if (quality == RT_BVH_QUALITY_LOW) { best = 0; cost = cj; bestBox = acc; break; }
+            if (cj < bestCost) { bestCost = cj; best = j; bestBox = acc; }
+        }
+        if (quality != RT_BVH_QUALITY_LOW) cost = bestCost;
+    }
+    const float sx = n.bmax[0] - n.bmin[0], sy = n.bmax[1] - n.bmin[1], sz = n.bmax[2] - n.bmin[2];
+    float parentCost = 0;
+    if (n.count != 0) { float area = sx * sy + sx * sz + sy * sz; parentCost = area * n.count; }
+    const bool split = cost < parentCost && n.depth < 32; /* BVH:101 */
+    splitFlag[a] = split ? 1 : 0;
+    n.left = -1;
+    if (split) {
+        if (best >= 0) { n.splitAxis = cands[(size_t)a * GB_NCAND + best].axis; n.splitPos = cands[(size_t)a * GB_NCAND + best].pos; chosen[a] = bestBox; }
+        else { n.splitAxis = 0; n.splitPos = 0.0f; chosen[a] = fallback; } /* bestSplitAxis/Pos stay (0, 0): BVH:204-205 */
+        n.nLeft = chosen[a].nLeft;
+    }
+}
+
+/* children of the splitting nodes: breadth-first slots firstChild + 2 * rank */
+__global__ void k_children(GNode* nodes, int first, int nActive, const int* splitFlag, const int* splitRank, const GBox* chosen, int firstChild, int* maxChildCount)
+{
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nActive || !splitFlag[a]) return;
+    {
+        const int nl = chosen[a].nLeft, nr = nodes[first + a].count - nl;
+        atomicMax(maxChildCount, nl > nr ? nl : nr); /* bounds the next level's partition chains */
+    }
+    GNode& n = nodes[first + a];
+    const int li = firstChild + 2 * splitRank[a];
+    n.left = li;
+    const GBox& b = chosen[a];
+    GNode l, r;
+    memset(&l, 0, sizeof(l));
+    memset(&r, 0, sizeof(r));
+    for (int k = 0; k < 3; k++) { l.bmin[k] = b.lmn[k]; l.bmax[k] = b.lmx[k]; r.bmin[k] = b.rmn[k]; r.bmax[k] = b.rmx[k]; }
+    l.start = n.start; l.count = b.nLeft; l.depth = n.depth + 1; l.left = -1;
+    r.start = n.start + b.nLeft; r.count = n.count - b.nLeft; r.depth = n.depth + 1; r.left = -1;
+    nodes[li] = l;
+    nodes[li + 1] = r;
+}
+
+/* ---- partition (see the header): flags, prefix sum, tape pointers, pointer jumping, scatter */
+__global__ void k_flags(const GNode* nodes, const int* triNode, const GTri* tris, int ntri, int* flag)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ntri) return;
+    const int nd = triNode[g];
+    int f = 0;
+    if (nd >= 0 && nodes[nd].left >= 0) f = tris[g].c[nodes[nd].splitAxis] < nodes[nd].splitPos ? 1 : 0;
+    flag[g] = f;
+}
+__global__ void k_tape(const GNode* nodes, const int* triNode, const int* flag, const int* S, int ntri, int* src)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ntri) return;
+    src[g] = g;
+    const int nd = triNode[g];
+    if (nd < 0 || nodes[nd].left < 0) return;
+    const GNode& n = nodes[nd];
+    /* every triangle before the first right-hand one goes left: firstR = start + (length of the leading run of lefts).
+     * nLeft lefts in all; the leading run is found from the prefix sums: position p is in it iff S[p] - S[start] == p - start
+     * and flag[p] == 1.  The first right-hand triangle is the first position where that fails. */
+    const int start = n.start;
+    const int cl = S[g] - S[start]; /* lefts before g */
+    if (flag[g]) {
+        /* r-th rotation -> tape position r; only rotations after the first right-hand triangle exist */
+        const int lead = cl == g - start; /* still inside the leading run: stays where it is */
+        if (!lead) {
+            /* firstR = start + (number of leading lefts) = the position of the first right-hand triangle: the leading run
+             * length L0 satisfies S[start + L0] - S[start] == L0 and flag[start + L0] == 0.  Lefts before g = cl, of which L0
+             * lead; r = cl - L0.  L0 is not known locally: recover it from the right-hand triangles (see k_tape2). */
+            src[g] = -1 - cl; /* provisional: resolved in k_tape2 once firstR of the node is known */
+        }
+    }
+}
+__global__ void k_first_right(GNode* nodes, const int* triNode, const int* flag, const int* S, int ntri, int* firstR)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ntri) return;
+    const int nd = triNode[g];
+    if (nd < 0 || nodes[nd].left < 0) return;
+    const int start = nodes[nd].start;
+    if (!flag[g] && S[g] - S[start] == g - start) firstR[nd] = g; /* exactly one right-hand triangle has only lefts before it */
+}
+__global__ void k_tape2(const GNode* nodes, const int* triNode, const int* firstR, int ntri, int* src)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ntri) return;
+    if (src[g] >= 0) return;
+    const int nd = triNode[g];
+    const int cl = -1 - src[g];
+    const int fr = firstR[nd];
+    const int lead = fr - nodes[nd].start; /* lefts in the leading run */
+    src[g] = fr + (cl - lead);             /* the r-th rotation copies tape position r = global position firstR + r */
+}
+__global__ void k_jump(int ntri, int* src, int* changed)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ntri) return;
+    const int s = src[g];
+    const int t = src[s];
+    if (t != s) {
+        src[g] = t;
+        if (changed) *changed = 1;
+    }
+}
+__global__ void k_scatter(const GNode* nodes, const int* triNode, const int* flag, const int* S, const int* firstR, const int* src, const GTri* tris, int ntri,
+                          GTri* outTris, int* outTriNode)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ntri) return;
+    const int nd = triNode[g];
+    if (nd < 0 || nodes[nd].left < 0) { /* finished leaf, or a node that became a leaf at this level */
+        outTris[g] = tris[g];
+        outTriNode[g] = -1;
+        return;
+    }
+    const GNode& n = nodes[nd];
+    const int start = n.start;
+    const int nLeft = n.nLeft;
+    if (flag[g]) { /* left-hand block is stable */
+        const int dest = start + (S[g] - S[start]);
+        outTris[dest] = tris[g];
+        outTriNode[dest] = n.left;
+    }
+    const int fr = firstR[nd];
+    if (fr >= 0 && g >= fr) { /* tape position p = g - firstR; the last nRight positions are the right-hand block */
+        const int p = g - fr;
+        const int laterL = nLeft - (fr - start);
+        if (p >= laterL) {
+            const int dest = start + nLeft + (p - laterL);
+            outTris[dest] = tris[src[g]];
+            outTriNode[dest] = n.left + 1;
+        }
+    }
+}
+
+/* ---- final numbering: subtree inner counts (bottom-up), pre-order ranks and node indices (top-down) */
+__global__ void k_inner_count(GNode* nodes, int first, int count)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    GNode& n = nodes[first + i];
+    n.innerCount = n.left >= 0 ? 1 + nodes[n.left].innerCount + nodes[n.left + 1].innerCount : 0;
+}
+__global__ void k_number(GNode* nodes, int first, int count)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    GNode& n = nodes[first + i];
+    if (n.left < 0) return;
+    GNode& l = nodes[n.left];
+    GNode& r = nodes[n.left + 1];
+    l.id = 1 + 2 * n.preIdx;
+    r.id = 2 + 2 * n.preIdx;
+    l.preIdx = n.preIdx + 1;
+    r.preIdx = n.preIdx + 1 + l.innerCount;
+}
+__global__ void k_emit(const GNode* nodes, int total, RtBVHNode* out, int* stats /* leafCount, depthSum, depthMax, depthMin, triMax, triMin, triSum */)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const GNode& n = nodes[i];
+    RtBVHNode o;
+    for (int k = 0; k < 3; k++) { o.boundsMin[k] = n.bmin[k]; o.boundsMax[k] = n.bmax[k]; }
+    if (n.left >= 0) {
+        o.startIndex = 1 + 2 * n.preIdx; /* BVH:165 */
+        o.triangleCount = i == 0 ? -1 : 0; /* the root keeps its constructor value (BVH:61) */
+    } else {
+        o.startIndex = n.start;
+        o.triangleCount = n.count;
+        atomicAdd(&stats[0], 1);
+        atomicAdd(&stats[1], n.depth);
+        atomicMax(&stats[2], n.depth);
+        atomicMin(&stats[3], n.depth);
+        atomicMax(&stats[4], n.count);
+        atomicMin(&stats[5], n.count);
+        atomicAdd(&stats[6], n.count);
+    }
+    out[n.id] = o;
+}
+__global__ void k_tri_index(const GTri* tris, int ntri, int* out)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < ntri) out[g] = tris[g].index;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { if (p) hipFree(p); }
+    template <typename T>
+    T* get(size_t n)
+    {
+        size_t bytes = n * sizeof(T);
+        if (bytes > cap) {
+            if (p) hipFree(p);
+            p = nullptr;
+            cap = 0;
+            size_t want = bytes + bytes / 4 + 256;
+            if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return nullptr; }
+            cap = want;
+        }
+        return (T*)p;
+    }
+};
+
+#define GB_TRY(call)                                   \
+    do {                                               \
+        hipError_t e_ = (call);                        \
+        if (e_ != hipSuccess) return RT_ERR_HIP;       \
+    } while (0)
+
+static inline int blocks(size_t n, int t = 256) { return (int)((n + t - 1) / t); }
+
+int build(int device, const float* verts, const float* normals, int n_verts, const int32_t* indices, int n_indices, int quality,
+          RtBVHNode* out_nodes, int* out_n_nodes, RtTriangle* out_tris, RtBvhStats* out_stats)
+{
+    if (!verts || !normals || !indices || !out_nodes || !out_n_nodes || !out_tris || n_verts < 0 || n_indices < 0 || n_indices % 3)
+        return RT_ERR_INVALID_ARG;
+    if (quality != RT_BVH_QUALITY_LOW && quality != RT_BVH_QUALITY_HIGH && quality != RT_BVH_QUALITY_DISABLED) return RT_ERR_INVALID_ARG;
+    for (int i = 0; i < n_indices; i++)
+        if (indices[i] < 0 || indices[i] >= n_verts) return RT_ERR_INVALID_ARG;
+    auto t0 = std::chrono::steady_clock::now();
+    const bool dbg = getenv("RT_BVH_DEBUG") != nullptr;
+    auto lap = [&](const char* what) {
+        if (dbg) fprintf(stderr, "[bvh-gpu] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RT_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return RT_ERR_INVALID_ARG;
+    GB_TRY(hipSetDevice(device));
+    const int ntri = n_indices / 3;
+
+    /* root bounds: BVH:53-58, in triangle order (host: one pass over the vertices of the indexed triangles) */
+    float rmn[3] = {GB_FMAX, GB_FMAX, GB_FMAX}, rmx[3] = {-GB_FMAX, -GB_FMAX, -GB_FMAX};
+    for (int t = 0; t < ntri; t++) {
+        const float* a = verts + 3 * indices[3 * t], * b = verts + 3 * indices[3 * t + 1], * c = verts + 3 * indices[3 * t + 2];
+        for (int k = 0; k < 3; k++) {
+            float mn = a[k] < b[k] ? (a[k] < c[k] ? a[k] : c[k]) : (b[k] < c[k] ? b[k] : c[k]);
+            float mx = a[k] > b[k] ? (a[k] > c[k] ? a[k] : c[k]) : (b[k] > c[k] ? b[k] : c[k]);
+            if (mn < rmn[k]) rmn[k] = mn;
+            if (mx > rmx[k]) rmx[k] = mx;
+        }
+    }
+
+    lap("validate + root box");
+    std::vector<int> order(ntri);
+    std::vector<RtBVHNode> nodesOut;
+    int statsH[7] = {0, 0, 0, INT32_MAX, 0, INT32_MAX, 0};
+    if (quality == RT_BVH_QUALITY_DISABLED || ntri == 0) { /* BVH:62-66 (and the empty mesh: Split makes the root a leaf) */
+        RtBVHNode root;
+        memcpy(root.boundsMin, rmn, 12);
+        memcpy(root.boundsMax, rmx, 12);
+        root.startIndex = 0;
+        root.triangleCount = ntri;
+        nodesOut.push_back(root);
+        for (int t = 0; t < ntri; t++) order[t] = 3 * t;
+        statsH[0] = (quality == RT_BVH_QUALITY_DISABLED) ? 0 : 1;
+        if (quality != RT_BVH_QUALITY_DISABLED) { statsH[3] = 0; statsH[5] = 0; }
+    } else {
+        /* device scratch is kept between calls (a scene build calls this once per mesh): hipMalloc/hipFree of twenty
+         * buffers would otherwise cost more than the build of a small mesh */
+        struct Pool { int device = -1; DevBuf b[22]; };
+        static thread_local Pool pool;
+        if (pool.device != device) { for (DevBuf& d : pool.b) { if (d.p) hipFree(d.p); d.p = nullptr; d.cap = 0; } pool.device = device; }
+        DevBuf &bVerts = pool.b[0], &bIdx = pool.b[1], &bTrisA = pool.b[2], &bTrisB = pool.b[3], &bNodeA = pool.b[4], &bNodeB = pool.b[5], &bFlag = pool.b[6],
+               &bScan = pool.b[7], &bSrc = pool.b[8], &bNodes = pool.b[9], &bCands = pool.b[10], &bPartial = pool.b[11], &bChosen = pool.b[12], &bCounts = pool.b[13],
+               &bBase = pool.b[14], &bChunkNode = pool.b[15], &bSplit = pool.b[16], &bRank = pool.b[17], &bFirstR = pool.b[18], &bTemp = pool.b[19], &bMisc = pool.b[20],
+               &bOut = pool.b[21];
+        float* dVerts = bVerts.get<float>((size_t)n_verts * 3 + 1);
+        int* dIdx = bIdx.get<int>((size_t)n_indices + 1);
+        GTri* trisA = bTrisA.get<GTri>(ntri);
+        GTri* trisB = bTrisB.get<GTri>(ntri);
+        int* nodeOfA = bNodeA.get<int>(ntri);
+        int* nodeOfB = bNodeB.get<int>(ntri);
+        int* flag = bFlag.get<int>((size_t)ntri + 1);
+        int* S = bScan.get<int>((size_t)ntri + 1);
+        int* src = bSrc.get<int>(ntri);
+        const size_t maxNodes = 2 * (size_t)ntri + 66; /* 2*ntri - 1 for a well-formed tree; empty-child chains are refused below */
+        GNode* nodes = bNodes.get<GNode>(maxNodes);
+        int* misc = bMisc.get<int>(16);
+        if (!dVerts || !dIdx || !trisA || !trisB || !nodeOfA || !nodeOfB || !flag || !S || !src || !nodes || !misc) return RT_ERR_OOM;
+        GB_TRY(hipMemcpy(dVerts, verts, sizeof(float) * 3 * (size_t)n_verts, hipMemcpyHostToDevice));
+        GB_TRY(hipMemcpy(dIdx, indices, sizeof(int) * (size_t)n_indices, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_prepare, dim3(blocks(ntri)), dim3(256), 0, 0, dVerts, dIdx, ntri, trisA, nodeOfA);
+        GNode root;
+        memset(&root, 0, sizeof(root));
+        memcpy(root.bmin, rmn, 12);
+        memcpy(root.bmax, rmx, 12);
+        root.start = 0; root.count = ntri; root.depth = 0; root.left = -1;
+        GB_TRY(hipMemcpy(nodes, &root, sizeof(GNode), hipMemcpyHostToDevice));
+
+        lap("alloc + upload");
+        std::vector<int> levelFirst;
+        int first = 0, nActive = 1, total = 1;
+        int levelMaxCount = ntri; /* largest active node of the current level */
+        GB_TRY(hipMemsetAsync(misc, 0, 16 * sizeof(int), 0));
+        size_t tempBytes = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, tempBytes, flag, S, ntri + 1);
+        void* temp = bTemp.get<char>(tempBytes + 256);
+        if (!temp) return RT_ERR_OOM;
+        while (nActive > 0) {
+            levelFirst.push_back(first);
+            GCand* cands = bCands.get<GCand>((size_t)nActive * GB_NCAND);
+            int* counts = bCounts.get<int>((size_t)nActive + 1);
+            int* base = bBase.get<int>((size_t)nActive + 1);
+            int* splitFlag = bSplit.get<int>((size_t)nActive + 1);
+            int* splitRank = bRank.get<int>((size_t)nActive + 1);
+            GBox* chosen = bChosen.get<GBox>(nActive);
+            if (!cands || !counts || !base || !splitFlag || !splitRank || !chosen) return RT_ERR_OOM;
+            hipLaunchKernelGGL(k_candidates, dim3(blocks(nActive)), dim3(256), 0, 0, nodes, first, nActive, quality, cands);
+            hipLaunchKernelGGL(k_chunk_counts, dim3(blocks(nActive)), dim3(256), 0, 0, nodes, first, nActive, counts);
+            GB_TRY(hipMemsetAsync(counts + nActive, 0, sizeof(int), 0));
+            size_t tb = 0;
+            hipcub::DeviceScan::ExclusiveSum(nullptr, tb, counts, base, nActive + 1);
+            if (tb > tempBytes) { tempBytes = tb; temp = bTemp.get<char>(tempBytes + 256); if (!temp) return RT_ERR_OOM; }
+            hipcub::DeviceScan::ExclusiveSum(temp, tb, counts, base, nActive + 1);
+            {
+                const int maxChunks = nActive + ntri / GB_CHUNK + 1; /* every node with candidates has ceil(count / 512) chunks */
+                int* chunkNode = bChunkNode.get<int>(maxChunks);
+                GBox* partial = bPartial.get<GBox>((size_t)maxChunks * GB_NCAND);
+                if (!chunkNode || !partial) return RT_ERR_OOM;
+                hipLaunchKernelGGL(k_chunk_map, dim3(blocks(nActive)), dim3(256), 0, 0, nodes, first, nActive, base, counts, chunkNode);
+                hipLaunchKernelGGL(k_sweep, dim3(maxChunks), dim3(64), 0, 0, nodes, first, chunkNode, base + nActive, cands, trisA, partial);
+                hipLaunchKernelGGL(k_choose, dim3(blocks(nActive)), dim3(256), 0, 0, nodes, first, nActive, quality, cands, partial, counts, chosen, splitFlag);
+            }
+            GB_TRY(hipMemsetAsync(splitFlag + nActive, 0, sizeof(int), 0));
+            tb = 0;
+            hipcub::DeviceScan::ExclusiveSum(nullptr, tb, splitFlag, splitRank, nActive + 1);
+            if (tb > tempBytes) { tempBytes = tb; temp = bTemp.get<char>(tempBytes + 256); if (!temp) return RT_ERR_OOM; }
+            hipcub::DeviceScan::ExclusiveSum(temp, tb, splitFlag, splitRank, nActive + 1);
+            int nSplit = 0;
+            GB_TRY(hipMemcpy(&nSplit, splitRank + nActive, sizeof(int), hipMemcpyDeviceToHost));
+            if ((size_t)total + 2 * (size_t)nSplit > maxNodes) return RT_ERR_SCENE; /* degenerate input: see rt_build_bvh */
+            int jumpPasses = 1; /* a tape chain is shorter than its node and halves every pass */
+            while ((1 << jumpPasses) < levelMaxCount) jumpPasses++;
+            if (nSplit > 0) {
+                int* firstR = bFirstR.get<int>(total);
+                if (!firstR) return RT_ERR_OOM;
+                hipLaunchKernelGGL(k_children, dim3(blocks(nActive)), dim3(256), 0, 0, nodes, first, nActive, splitFlag, splitRank, chosen, total, misc + 1);
+                GB_TRY(hipMemsetAsync(firstR, 0xff, sizeof(int) * (size_t)total, 0));
+                hipLaunchKernelGGL(k_flags, dim3(blocks(ntri)), dim3(256), 0, 0, nodes, nodeOfA, trisA, ntri, flag);
+                GB_TRY(hipMemsetAsync(flag + ntri, 0, sizeof(int), 0));
+                tb = tempBytes;
+                hipcub::DeviceScan::ExclusiveSum(temp, tb, flag, S, ntri + 1);
+                hipLaunchKernelGGL(k_first_right, dim3(blocks(ntri)), dim3(256), 0, 0, nodes, nodeOfA, flag, S, ntri, firstR);
+                hipLaunchKernelGGL(k_tape, dim3(blocks(ntri)), dim3(256), 0, 0, nodes, nodeOfA, flag, S, ntri, src);
+                hipLaunchKernelGGL(k_tape2, dim3(blocks(ntri)), dim3(256), 0, 0, nodes, nodeOfA, firstR, ntri, src);
+                /* pointer jumping: a chain is at most as long as its node has triangles and halves every pass */
+                /* (the bound is rarely reached: after every third pass a flag says whether any pointer still moved) */
+                for (int it = 0; it < jumpPasses;) {
+                    GB_TRY(hipMemsetAsync(misc + 2, 0, sizeof(int), 0));
+                    int k = 0;
+                    for (; k < 3 && it < jumpPasses; k++, it++)
+                        hipLaunchKernelGGL(k_jump, dim3(blocks(ntri)), dim3(256), 0, 0, ntri, src, k == 2 || it + 1 == jumpPasses ? misc + 2 : (int*)nullptr);
+                    if (it >= jumpPasses) break;
+                    int moved = 0;
+                    GB_TRY(hipMemcpy(&moved, misc + 2, sizeof(int), hipMemcpyDeviceToHost));
+                    if (!moved) break;
+                }
+                hipLaunchKernelGGL(k_scatter, dim3(blocks(ntri)), dim3(256), 0, 0, nodes, nodeOfA, flag, S, firstR, src, trisA, ntri, trisB, nodeOfB);
+                std::swap(trisA, trisB);
+                std::swap(nodeOfA, nodeOfB);
+            }
+            if (nSplit > 0) { /* children sizes of this level = the next level's node sizes */
+                GB_TRY(hipMemcpy(&levelMaxCount, misc + 1, sizeof(int), hipMemcpyDeviceToHost));
+                GB_TRY(hipMemsetAsync(misc + 1, 0, sizeof(int), 0));
+            }
+            first = total;
+            nActive = 2 * nSplit;
+            total += 2 * nSplit;
+        }
+        GB_TRY(hipGetLastError());
+        if (dbg) { hipDeviceSynchronize(); lap("levels"); }
+        /* numbering */
+        for (int l = (int)levelFirst.size() - 1; l >= 0; l--) {
+            const int lf = levelFirst[l], le = (l + 1 < (int)levelFirst.size()) ? levelFirst[l + 1] : total;
+            if (le > lf) hipLaunchKernelGGL(k_inner_count, dim3(blocks(le - lf)), dim3(256), 0, 0, nodes, lf, le - lf);
+        }
+        for (int l = 0; l < (int)levelFirst.size(); l++) {
+            const int lf = levelFirst[l], le = (l + 1 < (int)levelFirst.size()) ? levelFirst[l + 1] : total;
+            if (le > lf) hipLaunchKernelGGL(k_number, dim3(blocks(le - lf)), dim3(256), 0, 0, nodes, lf, le - lf);
+        }
+        RtBVHNode* dOut = bOut.get<RtBVHNode>(total);
+        if (!dOut) return RT_ERR_OOM;
+        GB_TRY(hipMemcpy(misc, statsH, sizeof(statsH), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_emit, dim3(blocks(total)), dim3(256), 0, 0, nodes, total, dOut, misc);
+        hipLaunchKernelGGL(k_tri_index, dim3(blocks(ntri)), dim3(256), 0, 0, trisA, ntri, S);
+        GB_TRY(hipGetLastError());
+        nodesOut.resize(total);
+        GB_TRY(hipMemcpy(nodesOut.data(), dOut, sizeof(RtBVHNode) * (size_t)total, hipMemcpyDeviceToHost));
+        GB_TRY(hipMemcpy(order.data(), S, sizeof(int) * (size_t)ntri, hipMemcpyDeviceToHost));
+        GB_TRY(hipMemcpy(statsH, misc, sizeof(statsH), hipMemcpyDeviceToHost));
+        lap("numbering + readback");
+    }
+    if (nodesOut.size() > 2 * (size_t)(ntri > 0 ? ntri : 1) || (ntri > 0 && statsH[0] > 0 && statsH[5] == 0)) { /* as rt_build_bvh */
+        *out_n_nodes = 0;
+        return RT_ERR_SCENE;
+    }
+    {   /* BVH:69-80: triangles in leaf order with vertex normals */
+        unsigned hc = std::thread::hardware_concurrency();
+        int threads = hc ? (int)(hc > 16 ? 16 : hc) : 1;
+        if (threads > ntri / 8192) threads = ntri / 8192;
+        if (threads < 1) threads = 1;
+        const int* ord = order.data();
+        auto fill = [=](int b0, int e0) {
+            for (int i = b0; i < e0; i++) {
+                const int b = ord[i];
+                RtTriangle& t = out_tris[i];
+                for (int k = 0; k < 3; k++) {
+                    t.posA[k] = verts[3 * indices[b + 0] + k];
+                    t.posB[k] = verts[3 * indices[b + 1] + k];
+                    t.posC[k] = verts[3 * indices[b + 2] + k];
+                    t.normA[k] = normals[3 * indices[b + 0] + k];
+                    t.normB[k] = normals[3 * indices[b + 1] + k];
+                    t.normC[k] = normals[3 * indices[b + 2] + k];
+                }
+            }
+        };
+        if (threads == 1) fill(0, ntri);
+        else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < threads; t++) pool.emplace_back(fill, (int)((long long)ntri * t / threads), (int)((long long)ntri * (t + 1) / threads));
+            for (auto& th : pool) th.join();
+        }
+    }
+    memcpy(out_nodes, nodesOut.data(), nodesOut.size() * sizeof(RtBVHNode));
+    *out_n_nodes = (int)nodesOut.size();
+    lap("triangle gather");
+    if (out_stats) {
+        memset(out_stats, 0, sizeof(*out_stats));
+        out_stats->triangleCount = statsH[6];
+        out_stats->totalNodeCount = (int)nodesOut.size() - (quality == RT_BVH_QUALITY_DISABLED ? 1 : 0);
+        out_stats->leafNodeCount = statsH[0];
+        out_stats->leafDepthMax = statsH[2];
+        out_stats->leafDepthMin = statsH[3];
+        out_stats->leafDepthSum = statsH[1];
+        out_stats->leafMaxTriCount = statsH[4];
+        out_stats->leafMinTriCount = statsH[5];
+        out_stats->quality = quality;
+        out_stats->timeMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return RT_OK;
+}
+
+} // namespace gbvh
+
+extern "C" int rt_build_bvh_gpu(int device_id, const float* verts, const float* normals, int n_verts, const int32_t* indices, int n_indices,
+                                int quality, RtBVHNode* out_nodes, int* out_n_nodes, RtTriangle* out_tris, RtBvhStats* out_stats)
+{
+    return gbvh::build(device_id, verts, normals, n_verts, indices, n_indices, quality, out_nodes, out_n_nodes, out_tris, out_stats);
+}

@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "rt_update_spheres", "rt_set_params", "rt_reset_accumulation", "rt_render_frame", "rt_render_frames",
     "rt_synchronize", "rt_get_frame", "rt_read_frame", "rt_read_accumulated", "rt_display", "rt_display_srgb8",
     "rt_write_accumulated", "rt_timer_begin", "rt_timer_end",
-    "rt_enable_stats", "rt_reset_counters", "rt_get_counters", "rt_build_bvh", "rt_build_bvh_mt", "rt_camera_view_params", "rt_version",
+    "rt_enable_stats", "rt_reset_counters", "rt_get_counters", "rt_build_bvh", "rt_build_bvh_mt", "rt_build_bvh_gpu", "rt_camera_view_params", "rt_version",
     "rt_debug_intersect", "rt_debug_math_eval", "rt_debug_phase_profile",
     "rt_flush",
     "rt_create_multi", "rt_destroy_multi", "rt_multi_count", "rt_multi_context", "rt_multi_resize", "rt_multi_upload_scene",
@@ -46,6 +46,8 @@ class HipApi(abi.CApi):
         "enable_stats": (C.c_int, [C.c_void_p, C.c_int]),
         "build_bvh_mt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.POINTER(C.c_int), C.c_void_p, C.POINTER(abi.RtBvhStats)]),
+        "build_bvh_gpu": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                    C.POINTER(C.c_int), C.c_void_p, C.POINTER(abi.RtBvhStats)]),
         "debug_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
         "debug_math_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
         "debug_phase_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -90,6 +92,22 @@ class HipApi(abi.CApi):
                                int(quality), int(threads), nodes.ctypes.data, C.byref(n_nodes), tris.ctypes.data, C.byref(stats))
         if rc != abi.RT_OK:
             raise abi.RtError(rc, "build_bvh_mt failed")
+        return nodes[: n_nodes.value].copy(), tris, stats.as_dict()
+
+    def build_bvh_arrays_gpu(self, verts, normals, indices, quality=abi.BVH_QUALITY_HIGH, device_id=0):
+        """rt_build_bvh_gpu: same output as build_bvh_arrays, built on the GPU."""
+        verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+        normals = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+        indices = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1)
+        ntri = len(indices) // 3
+        nodes = np.zeros(2 * max(1, ntri), dtype=abi.node_dtype)
+        tris = np.zeros(ntri, dtype=abi.triangle_dtype)
+        n_nodes = C.c_int(0)
+        stats = abi.RtBvhStats()
+        rc = self.build_bvh_gpu(int(device_id), verts.ctypes.data, normals.ctypes.data, len(verts), indices.ctypes.data, len(indices),
+                                int(quality), nodes.ctypes.data, C.byref(n_nodes), tris.ctypes.data, C.byref(stats))
+        if rc != abi.RT_OK:
+            raise abi.RtError(rc, "build_bvh_gpu failed")
         return nodes[: n_nodes.value].copy(), tris, stats.as_dict()
 
     def create_tracer(self, device_id=0):

@@ -193,6 +193,7 @@ class RayComputeManager:
         self.meshInfo = None
         self.hasBVH = False
         self.bvhStats = {}
+        self.bvhOnGpu = False  # CreateAllMeshData builds the BVHs with rt_build_bvh_gpu (same bytes)
         self._sized = False
 
     # RCM:61-67
@@ -266,8 +267,11 @@ class RayComputeManager:
             key = id(model.Mesh)
             if key not in meshLookup:
                 meshLookup[key] = (n_nodes, n_tris)
-                nd, tr, stats = self.api.build_bvh_arrays(model.Mesh.vertices, model.Mesh.normals,
-                                                          model.Mesh.triangles, self.bvhQuality)
+                # the tree is the reference's whichever builder makes it (byte-identical): the multi-threaded host
+                # builder, or — bvhOnGpu — rt_build_bvh_gpu
+                build = self.api.build_bvh_arrays_gpu if getattr(self, "bvhOnGpu", False) and hasattr(self.api, "build_bvh_arrays_gpu") \
+                    else self.api.build_bvh_arrays
+                nd, tr, stats = build(model.Mesh.vertices, model.Mesh.normals, model.Mesh.triangles, self.bvhQuality)
                 self.bvhStats[model.Mesh.name] = stats
                 tris.append(tr)
                 nodes.append(nd)

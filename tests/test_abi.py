@@ -59,6 +59,14 @@ def test_create_fails_loudly_without_gpu(pkg, api):
     assert "no CPU fallback" in str(e.value)
 
 
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful on a host without a GPU")
+def test_gpu_bvh_builder_fails_loudly_without_gpu(pkg, api):
+    m = pkg.meshes.cube()
+    with pytest.raises(pkg.abi.RtError) as e:
+        api.build_bvh_arrays_gpu(m.vertices, m.normals, m.triangles)
+    assert e.value.status == pkg.abi.RT_ERR_NO_DEVICE
+
+
 def test_host_helpers_work_without_gpu(pkg, api):
     vp = api.view_params(60.0, 16 / 9, 1.0)
     assert abs(vp[1] - 2 * 0.57735027) < 1e-6 and abs(vp[0] - vp[1] * 16 / 9) < 1e-6 and vp[2] == 1.0

@@ -150,3 +150,41 @@ def test_parallel_builder_is_byte_identical_for_any_thread_count(pkg, api, orc, 
         assert n0.tobytes() == n1.tobytes() and t0.tobytes() == t1.tobytes()
         s0.pop("timeMs"), s1.pop("timeMs")
         assert s0 == s1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("quality", [0, 1, 2])
+def test_gpu_builder_equals_host_builder(pkg, api, quality):
+    """rt_build_bvh_gpu (level-synchronous: ordered chunk reductions, prefix-sum + pointer-jumping partition,
+    pre-order numbering) emits the host builder's bytes: nodes, triangle order, statistics."""
+    cases = mesh_cases(pkg) + [pkg.meshes.icosphere(5, 1.0, 3), pkg.meshes.rounded_cube(14)]
+    empty = pkg.meshes.Mesh(np.zeros((3, 3), np.float32), np.zeros((3, 3), np.float32), np.zeros(0, np.int32), "empty")
+    for mesh in cases + [empty]:
+        n1, t1, s1 = api.build_bvh_arrays(mesh.vertices, mesh.normals, mesh.triangles, quality)
+        n2, t2, s2 = api.build_bvh_arrays_gpu(mesh.vertices, mesh.normals, mesh.triangles, quality)
+        assert len(n1) == len(n2), (mesh.name, quality, len(n1), len(n2))
+        assert n1.tobytes() == n2.tobytes(), (mesh.name, quality)
+        assert t1.tobytes() == t2.tobytes(), (mesh.name, quality)
+        s1.pop("timeMs"), s2.pop("timeMs")
+        assert s1 == s2, (mesh.name, quality, s1, s2)
+
+
+@pytest.mark.gpu
+def test_gpu_builder_big_meshes_and_refusal(pkg, api):
+    """81,920 and 327,680 triangles (the BASELINE config 4/5 mesh class and 4x that) byte-identical; input whose
+    reference-shaped tree is malformed is refused like on the host."""
+    import time
+    for sub, seed in ((6, 4), (7, 9)):
+        mesh = pkg.meshes.icosphere(sub, 1.0, seed)
+        t0 = time.perf_counter()
+        n1, t1, s1 = api.build_bvh_arrays(mesh.vertices, mesh.normals, mesh.triangles, 1)
+        t1s = time.perf_counter()
+        n2, t2, s2 = api.build_bvh_arrays_gpu(mesh.vertices, mesh.normals, mesh.triangles, 1)
+        t2s = time.perf_counter()
+        assert n1.tobytes() == n2.tobytes() and t1.tobytes() == t2.tobytes()
+        print(f"{len(t1)} triangles: host (threads auto) {1e3 * (t1s - t0):.1f} ms, gpu {1e3 * (t2s - t1s):.1f} ms (builder-internal {s1['timeMs']:.1f} / {s2['timeMs']:.1f})")
+    rng = np.random.default_rng(3)
+    v = (rng.uniform(-1, 1, (9, 3)) * 3e19).astype(np.float32)
+    with pytest.raises(pkg.abi.RtError) as e:
+        api.build_bvh_arrays_gpu(v, np.tile([[0, 1, 0]], (9, 1)), np.arange(9, dtype=np.int32), 1)
+    assert e.value.status == pkg.abi.RT_ERR_SCENE

@@ -340,6 +340,24 @@ def test_whole_full_size_frame_against_oracle(pkg, api, orc, cfg):
     assert viol == 0
 
 
+def test_scene_built_with_the_gpu_bvh_builder_renders_the_same_bits(pkg, api, orc):
+    """The BVHs of config 4 (81,920-triangle mesh + room) built on the GPU instead of on the host: same uploaded
+    buffers, hence the oracle's image."""
+    def tweak(mgr):
+        mgr.bvhOnGpu = True
+    g = api.create_tracer(0)
+    a, mg = render(pkg, api, g, 4, 160, 90, 2, tweak=tweak)
+    c = orc.create_tracer(8)
+    b, mc = render(pkg, orc, c, 4, 160, 90, 2)
+    assert mg.bvhOnGpu and set(mg.bvhStats) == set(mc.bvhStats)
+    for k in mg.bvhStats:
+        sa, sb = dict(mg.bvhStats[k]), dict(mc.bvhStats[k])
+        sa.pop("timeMs"), sb.pop("timeMs")
+        assert sa == sb, k
+    g.close(), c.close()
+    assert bits_equal(a, b)
+
+
 def test_config4_full_size_strip_sample(pkg, api, orc):
     """BASELINE config 4 as benchmarked: 1920x1080, depth of field on, the whole 81,920-triangle mesh."""
     sc = pkg.scenes.get(4)
