@@ -106,6 +106,8 @@ struct RtContext {
     Staging staging[8];
     int stagingNext = 0;
     uint64_t updateUploads = 0, updateSkips = 0; /* diagnostics: uploads enqueued / calls that changed nothing */
+    float* dStaging = nullptr; /* per-frame colours of a fused launch (rt_device.h, KArgs::staging) */
+    size_t stagingBytes = 0;
     void* dDisplay = nullptr;  /* scratch of the display pass, kept between calls (grows on demand) */
     size_t displayBytes = 0;
     hipEvent_t evStart = nullptr, evStop = nullptr;
@@ -297,6 +299,7 @@ void rt_destroy(RtContext* ctx)
     hipFree(ctx->dTileCost);
     hipFree(ctx->dTileOrder);
     hipFree(ctx->dDisplay);
+    hipFree(ctx->dStaging);
     for (RtContext::Staging& st : ctx->staging) {
         if (st.host) hipHostFree(st.host);
         if (st.done) hipEventDestroy(st.done);
@@ -1122,7 +1125,24 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
      * the other stream's kernel — different pixels, no dependence — picks up every slot that
      * frees, and the two streams settle into taking turns.  With a caller-provided stream the
      * caller's stream order is the contract, so there is one kernel on that stream. */
-    const int parts = (ctx->twoStreams && ctx->stream == ctx->ownStream && ctx->sideStream && tiles >= 2) ? 2 : 1;
+    /* several frames in one launch: (tile, frame) items, per-frame colours staged and summed in frame order afterwards */
+    const bool staged = nFrames > 1;
+    const size_t nPix = (size_t)ctx->localRows * ctx->W;
+    if (staged) {
+        const size_t need = (size_t)nFrames * nPix * 16;
+        if (ctx->stagingBytes < need) {
+            HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
+            hipFree(ctx->dStaging);
+            ctx->dStaging = nullptr;
+            ctx->stagingBytes = 0;
+            const size_t cap = (size_t)RT_MAX_FUSED_FRAMES * nPix * 16; /* grow once to the largest batch */
+            HIP_TRY(ctx, hipMalloc(&ctx->dStaging, cap));
+            ctx->stagingBytes = cap;
+        }
+        a.staging = ctx->dStaging;
+        a.stagingStride = (uint32_t)nPix;
+    }
+    const int parts = (!staged && ctx->twoStreams && ctx->stream == ctx->ownStream && ctx->sideStream && tiles >= 2) ? 2 : 1;
     if (parts == 2 && ctx->needFork) { /* the side stream follows what the main stream holds so far */
         HIP_TRY(ctx, hipEventRecord(ctx->evFork, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->sideStream, ctx->evFork, 0));
@@ -1130,9 +1150,11 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
     }
     for (int p = 0; p < parts; p++) {
         const int partTiles = (tiles - p + parts - 1) / parts;
-        int grid = (int)(resident < partTiles ? resident : partTiles);
-        if (ctx->gridOverride > 0) grid = ctx->gridOverride < partTiles ? ctx->gridOverride : partTiles;
+        const long long items = (long long)partTiles * (staged ? nFrames : 1);
+        int grid = (int)(resident < items ? resident : items);
+        if (ctx->gridOverride > 0) grid = (int)(ctx->gridOverride < items ? ctx->gridOverride : items);
         a.launchTiles = partTiles;
+        a.launchItems = (int)items;
         a.orderOffset = p;
         a.orderStride = parts;
         a.tileQueue = ctx->dTileQueue + p;
@@ -1146,8 +1168,15 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         hipLaunchKernelGGL(parts == 2 ? kernHalf : kern, dim3(grid), dim3(RT_WAVE), stackBytes, p == 0 ? ctx->stream : ctx->sideStream, a);
         HIP_TRY(ctx, hipGetLastError()); /* a refused launch ran no wave: the device counter did not move */
         /* every tile not taken by blockIdx is one successful fetch, and each of the grid waves overshoots once */
-        ctx->tileQueueNext[p] += (unsigned long long)partTiles + (a.queueStart ? (unsigned long long)grid : 0ull);
+        ctx->tileQueueNext[p] += (unsigned long long)items + (a.queueStart ? (unsigned long long)grid : 0ull);
         if (p == 1) ctx->sideDirty = true;
+    }
+    if (staged) {
+        int blocks = (int)((nPix + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(rtk::rt_accumulate_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const float4*)ctx->dStaging, nFrames, nPix, (float4*)a.accumulated,
+                           (float4*)a.frameRender, nPix);
+        HIP_TRY(ctx, hipGetLastError());
     }
     ctx->pixelFrames += (uint64_t)ctx->localRows * ctx->W * nFrames;
     return RT_OK;

@@ -719,6 +719,21 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
      * spatially close, but no lane idles while its tile mates finish their longer paths. */
     int poolX0 = 0, poolRow0 = 0, poolY0 = 0; /* pool tile: first column, first local row, first GLOBAL row */
     int poolPos = 0; /* next unassigned slot of the pool tile, 64 = exhausted */
+    int poolFrame = 0; /* the frame this pool tile is rendered for */
+    /* A launch of nFrames > 1 frames hands out (tile, frame) items — queue position q = tile position q / nFrames, frame
+     * q % nFrames — and a pixel's per-frame colours go to a staging slab that rt_accumulate_kernel adds up in frame order
+     * afterwards: the frames of one pixel are independent chains (each reseeds from Frame, RC:552), only their SUM has an
+     * order, so a launch is no longer as long as nFrames chains of its slowest pixel. */
+#define RT_ITEM(c, q, tilePos)                                  \
+    do {                                                        \
+        if ((c).nFrames > 1) {                                  \
+            tilePos = (q) / (c).nFrames;                        \
+            poolFrame = (c).frame0 + ((q) - tilePos * (c).nFrames); \
+        } else {                                                \
+            tilePos = (q);                                      \
+            poolFrame = (c).frame0;                             \
+        }                                                       \
+    } while (0)
     bool queueEmpty;
     /* wave-uniform, once per tile: every row of an 8-row tile lies in one strip (stripRows % 8 == 0);
      * cyclic strips: local strip ls is global strip ls*partCount + partIndex */
@@ -734,7 +749,9 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
     {
         const RT_CAS KArgs& c = cold_args();
         int tile = (int)blockIdx.x;
-        if (tile < c.launchTiles && c.nFrames > 0 && !c.queueStart) {
+        if (tile < c.launchItems && c.nFrames > 0 && !c.queueStart) {
+            const int q0_ = tile;
+            RT_ITEM(c, q0_, tile);
 #ifdef RT_TILE_PRIORITY
             if (c.tileOrder) {
                 const int T = c.launchTiles;
@@ -786,7 +803,11 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                 int next = 0;
                 if (lane == 0) next = (int)(atomicAdd(c.tileQueue, 1ull) - c.tileQueueBase);
                 next = __builtin_amdgcn_readfirstlane(next);
-                if (next >= c.launchTiles) { queueEmpty = true; break; }
+                if (next >= c.launchItems) { queueEmpty = true; break; }
+                {
+                    const int q_ = next;
+                    RT_ITEM(c, q_, next);
+                }
 #ifdef RT_TILE_PRIORITY
                 /* EXPERIMENT (-DRT_TILE_PRIORITY; measured within +-3 % of the shipped kernel on configs 2/3/5, whole
                  * image and 1/8 partitions, so not enabled): a launch cannot end before its longest pixel chains do, and a chain advances one
@@ -827,11 +848,11 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     PXU(PX_INDEX) = pixelIndex;
                     PXU(PX_LINEAR) = (uint32_t)lrow * c.W + (uint32_t)x;
                     PXU(PX_SEGSTART) = segments;
-                    PXU(PX_FRAME) = (uint32_t)c.frame0;
+                    PXU(PX_FRAME) = (uint32_t)poolFrame;
                     PXU(PX_SAMPLE) = 0;
                     PXF(PX_FPX) = focusPoint.x; PXF(PX_FPY) = focusPoint.y; PXF(PX_FPZ) = focusPoint.z;
                     PXF(PX_TIX) = 0.0f; PXF(PX_TIY) = 0.0f; PXF(PX_TIZ) = 0.0f;
-                    rng = pixelIndex + (uint32_t)c.frame0 * 719393u + (uint32_t)c.seed; /* RC:552 */
+                    rng = pixelIndex + (uint32_t)poolFrame * 719393u + (uint32_t)c.seed; /* RC:552 */
                     pathActive = false;
                     inTrav = false;
                     laneDone = false;
@@ -852,35 +873,29 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     /* RC:581 + RCC:18-23: finish this frame of this pixel */
                     const uint32_t pixLinear = PXU(PX_LINEAR);
                     const size_t pixOff = (size_t)pixLinear * 4;
-                    int frame = (int)PXU(PX_FRAME);
                     rt_f3 col = rt_v3(PXF(PX_TIX), PXF(PX_TIY), PXF(PX_TIZ)) * c.rcpSpp; /* / NumRaysPerPixel */
-                    if (frame == (c.frame0 + c.nFrames) - 1) {
-                        float4 o = make_float4(col.x, col.y, col.z, 1.0f);
-                        *reinterpret_cast<float4*>(c.frameRender + pixOff) = o;
-                    }
-                    if (c.accumulate) {
-                        float4 acc = *reinterpret_cast<float4*>(c.accumulated + pixOff);
-                        acc.x += col.x;
-                        acc.y += col.y;
-                        acc.z += col.z;
-                        acc.w += 1.0f;
-                        *reinterpret_cast<float4*>(c.accumulated + pixOff) = acc;
-                    }
-                    frame++;
-                    if (frame == (c.frame0 + c.nFrames)) {
-                        laneDone = true;
-                        if (c.tileCost) { /* longest serial chain of this tile's pixels: next frame's queue order */
-                            const uint32_t prow = pixLinear / c.W, pcol = pixLinear - prow * c.W;
-                            uint32_t* const slot = c.tileCost + (prow >> 3) * (uint32_t)c.tilesX + (pcol >> 3);
-                            const uint32_t chain = (segments - PXU(PX_SEGSTART)) / (uint32_t)c.nFrames;
-                            if (chain > *slot) atomicMax(slot, chain); /* the plain read may be stale (lower): then the atomic decides */
-                        }
+                    if (c.nFrames > 1) {
+                        /* one of several frames of this launch: the colour waits in its frame's slab for
+                         * rt_accumulate_kernel, which performs RCC:18-23 for the frames in order */
+                        const size_t slab = (size_t)((int)PXU(PX_FRAME) - c.frame0) * c.stagingStride;
+                        *reinterpret_cast<float4*>(c.staging + (slab + pixLinear) * 4) = make_float4(col.x, col.y, col.z, 1.0f);
                     } else {
-                        rng = PXU(PX_INDEX) + (uint32_t)frame * 719393u + (uint32_t)c.seed;
-                        sample = 0;
-                        PXU(PX_FRAME) = (uint32_t)frame;
-                        PXU(PX_SAMPLE) = 0;
-                        PXF(PX_TIX) = 0.0f; PXF(PX_TIY) = 0.0f; PXF(PX_TIZ) = 0.0f;
+                        *reinterpret_cast<float4*>(c.frameRender + pixOff) = make_float4(col.x, col.y, col.z, 1.0f);
+                        if (c.accumulate) {
+                            float4 acc = *reinterpret_cast<float4*>(c.accumulated + pixOff);
+                            acc.x += col.x;
+                            acc.y += col.y;
+                            acc.z += col.z;
+                            acc.w += 1.0f;
+                            *reinterpret_cast<float4*>(c.accumulated + pixOff) = acc;
+                        }
+                    }
+                    laneDone = true;
+                    if (c.tileCost) { /* longest serial chain of this tile's pixels: the next launches' queue order */
+                        const uint32_t prow = pixLinear / c.W, pcol = pixLinear - prow * c.W;
+                        uint32_t* const slot = c.tileCost + (prow >> 3) * (uint32_t)c.tilesX + (pcol >> 3);
+                        const uint32_t chain = segments - PXU(PX_SEGSTART);
+                        if (chain > *slot) atomicMax(slot, chain); /* the plain read may be stale (lower): then the atomic decides */
                     }
                 }
                 if (!laneDone && sample < c.spp) {
@@ -1142,6 +1157,27 @@ __global__ void rt_display_srgb8_kernel(const float4* src, uint32_t* dst, int wi
         size_t row = i / width, col = i - row * width;
         size_t o = flipY ? ((size_t)(rows - 1) - row) * width + col : i;
         dst[o] = r | (g << 8) | (b << 16) | 0xff000000u;
+    }
+}
+
+/* RCC:18-23 for the n frames of a fused launch, in frame order: AccumulatedRender += colour (alpha += 1) frame after
+ * frame — the same additions in the same order as n single-frame launches — and FrameRender = the last frame. */
+__global__ void rt_accumulate_kernel(const float4* staging, int nFrames, size_t stride, float4* accumulated, float4* frameRender, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        float4 acc = accumulated[i];
+        float4 c = make_float4(0.f, 0.f, 0.f, 1.f);
+        for (int f = 0; f < nFrames; f++) {
+            c = staging[(size_t)f * stride + i];
+            acc.x += c.x;
+            acc.y += c.y;
+            acc.z += c.z;
+            acc.w += 1.0f;
+        }
+        accumulated[i] = acc;
+        frameRender[i] = c;
     }
 }
 

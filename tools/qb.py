@@ -41,9 +41,10 @@ if os.environ.get("RT_PHASES"):
     for cfg in cfgs:
         tr = api.create_tracer(0)
         sc = pkg.scenes.get(cfg); mgr = sc.make_manager(tr, api); mgr.OnEnable(renderSeed=1)
-        tr.enable_stats(True); tr.reset_counters(); mgr.RenderFrames(1)
+        nph = int(os.environ.get("RT_PHASE_FRAMES", "1"))  # frames in the profiled launch (1 = the drain of a single-frame launch included)
+        tr.enable_stats(True); tr.reset_counters(); mgr.RenderFrames(nph)
         c = tr.counters(); ph = tr.phase_profile()
-        print(f"config {cfg} phase profile (1 frame, {c['segments']} segments):")
+        print(f"config {cfg} phase profile ({nph} frame(s) in one launch, {c['segments']} segments):")
         for k, (e, l) in ph.items():
             if k == 'filter_violations': print('   filter_violations', e); continue
             if e: print(f"   {k:14s} wave-execs {e:12d}  lanes {l:13d}  util {l/(64*e):.3f}  execs/segment*64 {e*64/c['segments']:.2f}")
