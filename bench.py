@@ -25,9 +25,11 @@ after the timed steps, and is reported as `gather_ms`.  `--scaling weak` grows t
 roofline (rank 0, N = 1): the kernel is VALU-issue bound, not memory bound, so
 `bound` = "valu": achieved = SQ_INSTS_VALU per launch / average launch time, peak = 256 CU x 4 SIMD x
 2.4 GHz / 2 cycles per wave64 instruction, frac = achieved/peak x lane utilisation
-(SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)).  The counters come from rocprofv3 PMC passes over a
-child run of THIS script in the same invocation (separate passes for the SQ counters, FETCH_SIZE and
-WRITE_SIZE); if rocprofv3 is unavailable the committed profiles/ summary is replayed and labelled so.
+(SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)).  A "launch" is the dominant one of the timed region: the
+fused launch of up to 16 frames that back-to-back rt_render_frame calls leave as (`frames_per_launch`).  The
+counters come from rocprofv3 PMC passes over a child run of THIS script in the same invocation (separate passes
+for the SQ counters, FETCH_SIZE and WRITE_SIZE); if rocprofv3 is unavailable the committed profiles/ summary
+is replayed and labelled so.
 
 Prints ONE JSON line on rank 0.
 """
@@ -150,23 +152,20 @@ def pmc_child(args):
     sc = pkg.scenes.get(args.config)
     mgr = sc.make_manager(tr, api)
     mgr.OnEnable(renderSeed=1)
-    for _ in range(args.warmup):
-        mgr.RenderFrame()
-    tr.synchronize()
-    for _ in range(args.steps):
-        tr.render_frame()
+    for _ in range(args.warmup + args.steps):   # every trace-kernel dispatch of the child is one fused launch of --frames-per-launch frames
+        tr.render_frames(args.frames_per_launch)
     tr.synchronize()
     tr.close()
 
 
-def run_pmc_pass(counters, config, steps, warmup, outdir, tag):
+def run_pmc_pass(counters, config, steps, warmup, outdir, tag, fpl=16):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
     d = os.path.join(outdir, tag)
     cmd = [exe, "--pmc"] + counters + ["--kernel-trace", "-d", d, "-o", "pmc", "--",
                                        sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", str(config),
-                                       "--steps", str(steps), "--warmup", str(warmup)]
+                                       "--steps", str(steps), "--warmup", str(warmup), "--frames-per-launch", str(fpl)]
     env = dict(os.environ, TMPDIR="/tmp")
     try:
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
@@ -188,19 +187,19 @@ def run_pmc_pass(counters, config, steps, warmup, outdir, tag):
     return res or None
 
 
-def collect_pmc(config, steps, warmup, with_traffic):
+def collect_pmc(config, steps, warmup, with_traffic, fpl=16):
     """SQ pass (+ FETCH_SIZE and WRITE_SIZE passes) over child runs of this script; None if rocprofv3 cannot run."""
     out = tempfile.mkdtemp(prefix="rt_pmc_", dir="/tmp")
     try:
-        sq = run_pmc_pass(["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES"], config, steps, warmup, out, "sq")
+        sq = run_pmc_pass(["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES"], config, steps, warmup, out, "sq", fpl)
         if not sq or "SQ_INSTS_VALU" not in sq:
             return None
         r = {"valu_insts_per_launch": sq["SQ_INSTS_VALU"]["avg"],
              "lane_util": sq["SQ_THREAD_CYCLES_VALU"]["avg"] / (64.0 * sq["SQ_ACTIVE_INST_VALU"]["avg"]),
              "launches_sampled": sq["SQ_INSTS_VALU"]["n"]}
         if with_traffic:
-            rd = run_pmc_pass(["FETCH_SIZE"], config, steps, warmup, out, "rd")
-            wr = run_pmc_pass(["WRITE_SIZE"], config, steps, warmup, out, "wr")
+            rd = run_pmc_pass(["FETCH_SIZE"], config, steps, warmup, out, "rd", fpl)
+            wr = run_pmc_pass(["WRITE_SIZE"], config, steps, warmup, out, "wr", fpl)
             if rd and wr and "FETCH_SIZE" in rd and "WRITE_SIZE" in wr:
                 # MI355X_MICROARCH.md §HBM: KiB units; gfx950 FETCH_SIZE counts wide coalesced reads at 1/2 -> x2; WRITE_SIZE as is
                 r["hbm_read_bytes"] = rd["FETCH_SIZE"]["avg"] * 1024 * 2
@@ -210,21 +209,22 @@ def collect_pmc(config, steps, warmup, with_traffic):
         shutil.rmtree(out, ignore_errors=True)
 
 
-def replayed_pmc(config):
+def replayed_pmc(config, fpl=16):
     prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if not os.path.exists(prof):
         return None
     with open(prof) as f:
         p = json.load(f).get(f"config{config}_n1")
-    if not p:
+    if not p or p.get("frames_per_launch", 1) != fpl:
         return None
     return {"valu_insts_per_launch": p["valu_insts"], "lane_util": p["valu_lane_utilisation"],
             "hbm_read_bytes": p.get("read_bytes"), "hbm_write_bytes": p.get("write_bytes"),
             "replayed_from": "profiles/pmc_summary.json (" + p.get("source", "?") + ")"}
 
 
-def single_launch_ms(pkg, api, dev_index, scene_id, W, H, steps, warmup, partition=None):
-    """Average duration of ONE kernel per frame on one stream (RT_TWO_STREAMS=0), HIP events on the launch stream."""
+def launch_profile(pkg, api, dev_index, scene_id, W, H, launches, frames_per_launch, partition=None):
+    """Average duration of one trace-kernel launch of `frames_per_launch` frames, one kernel per launch on one stream
+    (RT_TWO_STREAMS=0, RT_COALESCE=0), HIP events on the launch stream.  Returns (ms per launch, segments per launch)."""
     prev = {k: os.environ.get(k) for k in ("RT_TWO_STREAMS", "RT_COALESCE")}
     os.environ["RT_TWO_STREAMS"] = "0"
     os.environ["RT_COALESCE"] = "0"
@@ -241,17 +241,16 @@ def single_launch_ms(pkg, api, dev_index, scene_id, W, H, steps, warmup, partiti
     sc = pkg.scenes.get(scene_id)
     m = sc.make_manager(t, api, W, H)
     m.OnEnable(renderSeed=1)
-    for _ in range(warmup):
-        m.RenderFrame()
+    t.render_frames(frames_per_launch)
     t.synchronize()
     t.reset_counters()
     t.timer_begin()
-    for _ in range(steps):
-        t.render_frame()
+    for _ in range(launches):
+        t.render_frames(frames_per_launch)
     t.timer_end()
     c = t.counters()
     t.close()
-    return c["gpuMs"] / steps, c["segments"]
+    return c["gpuMs"] / launches, c["segments"] / launches
 
 
 def valu_roofline(pmc, launch_ms, segments_per_launch):
@@ -284,6 +283,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the BVH-workload roofline block (configs 3 and 4)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--frames-per-launch", type=int, default=16, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.pmc_child:
@@ -399,19 +399,17 @@ def main():
                    "value": tracer.counters()["segments"] / batched_elapsed / 1e6, "unit": "Mrays/s",
                    "ms_per_frame": batched_elapsed / args.steps * 1e3}
 
-    # ---- roofline pass (rank 0): the timed pass above may launch every frame as two kernels on two
-    # streams that overlap in time, so "duration of one launch" is not defined there.  The same K
-    # frames are rendered once more by a context restricted to ONE kernel per frame on one stream
-    # (RT_TWO_STREAMS=0): HIP events around those K launches give the kernel's average launch duration,
-    # the figure rocprofv3 --kernel-trace reports for the same mode (profiles/).
-    single_ms = None
+    # ---- roofline pass (rank 0): the dominant kernel of the timed region is the FUSED launch (K back-to-back
+    # rt_render_frame calls leave as launches of up to 16 frames).  The same frames are rendered once more by a context
+    # restricted to one kernel per launch on one stream, `fpl` frames per launch: HIP events around those launches give
+    # the kernel's average launch duration, the figure rocprofv3 --kernel-trace reports for the same mode (profiles/).
+    # A second short pass at one frame per launch gives the reference's dispatch granularity for comparison.
+    single_ms = launch_ms = launch_segments = None
+    fpl = max(1, min(16, args.steps))
     if rank == 0:
-        if os.environ.get("RT_TWO_STREAMS") == "0" and os.environ.get("RT_COALESCE") == "0":
-            single_ms = timed["gpuMs"] / args.steps
-        else:
-            single_ms, seg1 = single_launch_ms(pkg, api, dev_index, args.config, W, H, args.steps, args.warmup,
-                                               (pkg.dist.STRIP_ROWS, rank, world) if tiled else None)
-            assert seg1 == segments, (seg1, segments)
+        part = (pkg.dist.STRIP_ROWS, rank, world) if tiled else None
+        launch_ms, launch_segments = launch_profile(pkg, api, dev_index, args.config, W, H, max(2, min(6, args.steps // fpl + 1)), fpl, part)
+        single_ms, seg1 = launch_profile(pkg, api, dev_index, args.config, W, H, min(args.steps, 8), 1, part)
 
     # ---- readback: the one collective of the multi-GPU path
     gather_ms = None
@@ -450,19 +448,20 @@ def main():
         # ---- VALU roofline of the dominant (only) kernel
         pmc = None
         if world == 1 and not args.no_pmc:
-            pmc = collect_pmc(args.config, min(args.steps, 6), 1, with_traffic=True)
-        if pmc is None:
-            pmc = replayed_pmc(args.config)
+            pmc = collect_pmc(args.config, 3, 1, with_traffic=True, fpl=fpl)
+        if pmc is None and world == 1:
+            pmc = replayed_pmc(args.config, fpl)
         roof = None
         if pmc is not None:
-            roof = valu_roofline(pmc, single_ms, segments / args.steps)
-            roof["kernel"] = ("rt_trace_kernel<false, *>: whole-frame launches (one kernel per frame, RT_TWO_STREAMS=0 pass); the "
-                              "half-frame launches of the timed pass run the same code as rt_trace_half_kernel")
+            roof = valu_roofline(pmc, launch_ms, launch_segments)
+            roof["frames_per_launch"] = fpl
+            roof["kernel"] = (f"rt_trace_kernel<false, *>, launches of {fpl} frames ((tile, frame) work items; one kernel per launch on one "
+                              "stream in the roofline pass) — the form the timed K back-to-back rt_render_frame calls are launched in")
             roof["peak_derivation"] = "256 CU x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)"
             roof["secondary_hbm_algorithmic"] = {
                 "what": "SURVEY.md 8(d) algorithmic bytes (the reference loop's loads for the counted work) / launch time; the scene is "
                         "SGPR/L2 resident, so this is NOT a roof and may exceed 8 TB/s — kept for continuity with round 1",
-                "bytes_per_launch": my_bytes, "GBps": my_bytes / (single_ms * 1e-3) / 1e9}
+                "bytes_per_launch": my_bytes * fpl, "GBps": my_bytes * fpl / (launch_ms * 1e-3) / 1e9}
         parity = parity_check(pkg, api, dev_index, args.config, W, H, (3, H // 16, H // 8 - 2)) if world == 1 else None
         out = {
             "metric": f"Mrays/s at {W}x{H}, {spp} spp, {mb} bounces; per-channel L2 vs reference",
@@ -491,12 +490,14 @@ def main():
             "ms_per_step_with_initframe": init_elapsed / args.steps * 1e3,
             "gather_ms": gather_ms, "gather_error": gather_error, "gathered_image_complete": gather_alpha_ok,
             "launches": ("K x rt_render_frame, back to back: the library starts an idle GPU at once (frame 1: 2 kernels on 2 streams, disjoint "
-                         "tile halves) and holds frames requested while earlier ones still execute back, up to 16, to launch them fused "
-                         "(each pixel runs its frames back to back; same bits); RT_COALESCE=0 = one launch per call")
+                         "tile halves) and holds frames requested while earlier ones still execute back, up to 16, to launch them fused as "
+                         "(tile, frame) work items whose per-frame colours are added in frame order afterwards (same bits); "
+                         "RT_COALESCE=0 = one launch per call")
                         if os.environ.get("RT_COALESCE") != "0" else
                         ("2 kernels per frame on 2 streams (disjoint tile halves, overlapping in time)"
                          if os.environ.get("RT_TWO_STREAMS") != "0" else "1 kernel per frame"),
             "value_one_kernel_per_frame": (segments / args.steps / (single_ms * 1e-3) / 1e6) if single_ms else None,
+            "value_fused_launches_one_stream": (launch_segments / (launch_ms * 1e-3) / 1e6) if launch_ms else None,
             "batched_api": batched,
             "parity": parity if parity is not None else "checked at N=1 (pytest -m gpu and the N=1 bench line)",
             "roofline": roof,
@@ -506,12 +507,13 @@ def main():
             sec = {}
             for cfg in (3, 4):
                 sc2 = pkg.scenes.get(cfg)
-                ms2, seg2 = single_launch_ms(pkg, api, dev_index, cfg, sc2.width, sc2.height, 6, 1)
-                p2 = (None if args.no_pmc else collect_pmc(cfg, 4, 1, with_traffic=False)) or replayed_pmc(cfg)
+                ms2, seg2 = launch_profile(pkg, api, dev_index, cfg, sc2.width, sc2.height, 2, 16)
+                p2 = (None if args.no_pmc else collect_pmc(cfg, 2, 1, with_traffic=False, fpl=16)) or replayed_pmc(cfg)
                 if p2 is None:
                     continue
-                r2 = valu_roofline(p2, ms2, seg2 / 6)
-                r2["mrays_per_s_one_kernel_per_frame"] = seg2 / 6 / (ms2 * 1e-3) / 1e6
+                r2 = valu_roofline(p2, ms2, seg2)
+                r2["frames_per_launch"] = 16
+                r2["mrays_per_s_fused_launches"] = seg2 / (ms2 * 1e-3) / 1e6
                 r2["workload"] = f"{sc2.name}: {sc2.width}x{sc2.height}, {sc2.unique_triangles()} triangles, BASELINE.json configs[{cfg - 1}]"
                 sec[f"config{cfg}"] = r2
             out["secondary"] = sec

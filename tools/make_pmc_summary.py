@@ -1,5 +1,6 @@
 """Build profiles/pmc_summary.json (read by bench.py for roofline.traffic) from tools/prof.sh outputs:
-usage: python tools/make_pmc_summary.py <key>=<gpurun_out/prof_dir> ..."""
+usage: [FPL=16] python tools/make_pmc_summary.py <key>=<gpurun_out/prof_dir> ...   (FPL = frames per launch of the profiled runs,
+tools/prof.sh's third argument; bench.py only replays an entry whose frames_per_launch matches its roofline pass)"""
 import json, os, sys
 out = {}
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_summary.json")
@@ -12,6 +13,7 @@ for arg in sys.argv[1:]:
     rd = p["FETCH_SIZE"]["avg"] * 1024 * 2      # KiB -> B, x2: gfx950 FETCH_SIZE under-count (MI355X_MICROARCH.md §HBM)
     wr = p["WRITE_SIZE"]["avg"] * 1024
     out[key] = {
+        "frames_per_launch": int(os.environ.get("FPL", "16")),
         "hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
         "l2_hit_rate": p["TCC_HIT_sum"]["avg"] / (p["TCC_HIT_sum"]["avg"] + p["TCC_MISS_sum"]["avg"]),
         "valu_insts": p["SQ_INSTS_VALU"]["avg"], "valu_lane_utilisation": p["SQ_THREAD_CYCLES_VALU"]["avg"] / (p["SQ_ACTIVE_INST_VALU"]["avg"] * 64),
