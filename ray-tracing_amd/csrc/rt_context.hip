@@ -20,7 +20,9 @@
 
 #include "rt_kernels.h"
 
+#ifndef RT_MAX_FUSED_FRAMES
 #define RT_MAX_FUSED_FRAMES 16
+#endif
 #define RT_VERSION_STRING "raytrace_hip gfx950 abi=1"
 
 static thread_local char g_err[512] = "";
@@ -1141,6 +1143,9 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         }
         a.staging = ctx->dStaging;
         a.stagingStride = (uint32_t)nPix;
+        /* the frames before this launch may have left a half-frame kernel on the side stream that still adds into
+         * the accumulation buffer: rt_accumulate_kernel must come after it */
+        (void)joined(ctx);
     }
     const int parts = (!staged && ctx->twoStreams && ctx->stream == ctx->ownStream && ctx->sideStream && tiles >= 2) ? 2 : 1;
     if (parts == 2 && ctx->needFork) { /* the side stream follows what the main stream holds so far */
