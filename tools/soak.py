@@ -11,7 +11,7 @@ pkg = g.load_package(); api = pkg.load_library()
 
 
 def run(plain):
-    for k, v in (("RT_TWO_STREAMS", "0"), ("RT_FUSE_FRAMES", "0"), ("RT_LPT", "0")):
+    for k, v in (("RT_TWO_STREAMS", "0"), ("RT_FUSE_FRAMES", "0"), ("RT_LPT", "0"), ("RT_COALESCE", "0")):
         if plain:
             os.environ[k] = v
         else:
