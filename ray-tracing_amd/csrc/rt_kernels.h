@@ -967,6 +967,13 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                 float uSpec = 0.0f;
                 if (!isGlass) uSpec = rt_random_value(&rng); /* RC:521 */
                 const rt_f3 diffuseDir = rt_normalize(normal + rand_direction(&rng)); /* RC:509 / RC:525 */
+                /* Both branches end in normalize(lerp(A, B, t)) of a direction pair: opaque (diffuseDir, reflect, smoothness x
+                 * isSpecular), glass either (diffuseDir, reflect, specularProbability) or (-diffuseDir, refract, smoothness).  The
+                 * reference normalises both glass candidates and keeps one (RC:511-516); only the kept one is observable, so the
+                 * branches just pick (A, B, t) and ONE lerp + normalize follows for all hit lanes. */
+                const rt_f3 specularDir = rt_reflect(rdir, normal); /* == the glass branch's reflectDir, RC:419-422 */
+                rt_f3 lerpA = diffuseDir, lerpB = specularDir;
+                float lerpT;
                 if (isGlass) {
                     phase_mark<STATS>(st, PH_GLASS);
                     if (h.backface) { /* RC:502 */
@@ -975,23 +982,24 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     }
                     float iorCurrent = h.backface ? mat.ior : 1.0f;
                     float iorNext = h.backface ? 1.0f : mat.ior;
-                    rt_f3 reflectDir = rdir - (2 * rt_dot(rdir, normal)) * normal; /* RC:419-422 */
-                    rt_f3 refractDir = refract_dir(rdir, normal, iorCurrent, iorNext);
-                    float reflectWeight = reflectance(rdir, normal, iorCurrent, iorNext);
-                    reflectDir = rt_normalize(rt_lerp3(diffuseDir, reflectDir, mat.specularProbability));
-                    refractDir = rt_normalize(rt_lerp3(-diffuseDir, refractDir, mat.smoothness));
-                    bool followReflection = rt_random_value(&rng) <= reflectWeight; /* RC:515 */
-                    rdir = followReflection ? reflectDir : refractDir;
-                    rpos = hpos + (0.001f * normal) * rt_sign(rt_dot(normal, rdir));
+                    const rt_f3 refractDir = refract_dir(rdir, normal, iorCurrent, iorNext);
+                    const float reflectWeight = reflectance(rdir, normal, iorCurrent, iorNext);
+                    const bool followReflection = rt_random_value(&rng) <= reflectWeight; /* RC:515 */
+                    lerpT = mat.specularProbability;
+                    if (!followReflection) {
+                        lerpA = -diffuseDir;
+                        lerpB = refractDir;
+                        lerpT = mat.smoothness;
+                    }
                 } else {
-                    bool isSpecular = mat.specularProbability >= uSpec;
-                    rpos = hpos + (normal * 0.001f);
-                    rt_f3 specularDir = rt_reflect(rdir, normal);
-                    rdir = rt_normalize(rt_lerp3(diffuseDir, specularDir, mat.smoothness * (isSpecular ? 1.0f : 0.0f)));
+                    const bool isSpecular = mat.specularProbability >= uSpec;
+                    lerpT = mat.smoothness * (isSpecular ? 1.0f : 0.0f);
                     rt_f3 emitted = rt_v3(mat.emissionCol[0], mat.emissionCol[1], mat.emissionCol[2]) * mat.emissionStrength;
                     pathLight = pathLight + emitted * transmittance;
                     transmittance = transmittance * material_colour(mat, hpos, normal, isSpecular);
                 }
+                rdir = rt_normalize(rt_lerp3(lerpA, lerpB, lerpT));
+                rpos = isGlass ? hpos + (0.001f * normal) * rt_sign(rt_dot(normal, rdir)) : hpos + (normal * 0.001f);
                 /* RC:535-538 Russian roulette */
                 float p = rt_max(transmittance.x, rt_max(transmittance.y, transmittance.z));
                 if (rt_random_value(&rng) >= p) {
