@@ -108,6 +108,19 @@ struct RtContext {
     Staging staging[8];
     int stagingNext = 0;
     uint64_t updateUploads = 0, updateSkips = 0; /* diagnostics: uploads enqueued / calls that changed nothing */
+    /* Launch tuner (scheduling only, results do not depend on it): the suspension threshold of the traversal loop has two
+     * good values, 3/8 and 4/8 of the entrants, and which one is faster depends on how much of a segment is traversal
+     * (config 3: 3/8 by 9 %, config 6: 4/8 by 2 %).  Once 48 frames have been rendered, fused launches of >= 8 frames
+     * alternate between them, timed with events that are only polled, never waited for; after 3 samples each the
+     * faster stays (RT_SUSPEND=3|4 pins it). */
+    struct Tuner {
+        int decided = 3;       /* value in use once `done` */
+        bool done = false;
+        double ms[2] = {0, 0}; /* accumulated ms per frame for suspendNum 3, 4 */
+        int n[2] = {0, 0};
+        int next = 0;          /* which candidate the next measured launch uses */
+        struct Probe { hipEvent_t start = nullptr, stop = nullptr; int cand = 0, frames = 0; bool live = false; } probe[6];
+    } tuner;
     float* dStaging = nullptr; /* per-frame colours of a fused launch (rt_device.h, KArgs::staging) */
     size_t stagingBytes = 0;
     void* dDisplay = nullptr;  /* scratch of the display pass, kept between calls (grows on demand) */
@@ -302,6 +315,10 @@ void rt_destroy(RtContext* ctx)
     hipFree(ctx->dTileOrder);
     hipFree(ctx->dDisplay);
     hipFree(ctx->dStaging);
+    for (auto& pr : ctx->tuner.probe) {
+        if (pr.start) hipEventDestroy(pr.start);
+        if (pr.stop) hipEventDestroy(pr.stop);
+    }
     for (RtContext::Staging& st : ctx->staging) {
         if (st.host) hipHostFree(st.host);
         if (st.done) hipEventDestroy(st.done);
@@ -892,6 +909,13 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
     ctx->hModels.assign(models, models + n_models);
     ctx->hRootCodes = rootCodes;
     ctx->haveScene = true;
+    ctx->tuner.done = getenv("RT_SUSPEND") != nullptr; /* RT_SUSPEND=3|4 pins the threshold (tests, A/B runs) */
+    ctx->tuner.decided = ctx->tuner.done ? atoi(getenv("RT_SUSPEND")) : 3;
+    if (ctx->tuner.decided < 1 || ctx->tuner.decided > 7) ctx->tuner.decided = 3;
+    ctx->tuner.ms[0] = ctx->tuner.ms[1] = 0;
+    ctx->tuner.n[0] = ctx->tuner.n[1] = 0;
+    ctx->tuner.next = 0;
+    for (auto& pr : ctx->tuner.probe) pr.live = false;
     return RT_OK;
 }
 
@@ -1147,6 +1171,37 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
          * the accumulation buffer: rt_accumulate_kernel must come after it */
         (void)joined(ctx);
     }
+    /* launch tuner: collect finished probes, pick this launch's threshold */
+    RtContext::Tuner& tn = ctx->tuner;
+    RtContext::Tuner::Probe* probe = nullptr;
+    a.suspendNum = tn.decided;
+    if (!tn.done && !ctx->flatScene) {
+        for (auto& pr : tn.probe)
+            if (pr.live && hipEventQuery(pr.stop) == hipSuccess) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, pr.start, pr.stop) == hipSuccess && pr.frames > 0) {
+                    tn.ms[pr.cand] += ms / pr.frames;
+                    tn.n[pr.cand]++;
+                }
+                pr.live = false;
+            }
+        if (tn.n[0] >= 3 && tn.n[1] >= 3) {
+            tn.decided = (tn.ms[1] / tn.n[1] < 0.99 * (tn.ms[0] / tn.n[0])) ? 4 : 3; /* 4/8 has to win by more than the noise */
+            tn.done = true;
+            a.suspendNum = tn.decided;
+            if (ctx->verbose) fprintf(stderr, "[raytrace_hip] launch tuner: 3/8 %.3f ms/frame, 4/8 %.3f ms/frame -> %d/8\n", tn.ms[0] / tn.n[0], tn.ms[1] / tn.n[1], tn.decided);
+        } else if (staged && nFrames >= 8 && !ctx->stats && ctx->framesSinceResize >= 48) { /* only long progressive renders are tuned: short runs keep 3/8 */
+            for (auto& pr : tn.probe)
+                if (!pr.live) { probe = &pr; break; }
+            if (probe) {
+                if (!probe->start) { hipEventCreate(&probe->start); hipEventCreate(&probe->stop); }
+                probe->cand = tn.next;
+                probe->frames = nFrames;
+                tn.next ^= 1;
+                a.suspendNum = probe->cand ? 4 : 3;
+            }
+        }
+    }
     const int parts = (!staged && ctx->twoStreams && ctx->stream == ctx->ownStream && ctx->sideStream && tiles >= 2) ? 2 : 1;
     if (parts == 2 && ctx->needFork) { /* the side stream follows what the main stream holds so far */
         HIP_TRY(ctx, hipEventRecord(ctx->evFork, ctx->stream));
@@ -1170,7 +1225,9 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         a.queueStart = parts == 2 ? 1 : 0;
         a.tileQueueBase = ctx->tileQueueNext[p] - (a.queueStart ? 0ull : (unsigned long long)grid);
         if (ctx->verbose) fprintf(stderr, "[raytrace_hip] launch variant=%d part=%d/%d tiles=%d grid=%d perCU=%d lds=%zu\n", variant, p, parts, partTiles, grid, ctx->occPerCU[variant], stackBytes);
+        if (probe) hipEventRecord(probe->start, ctx->stream);
         hipLaunchKernelGGL(parts == 2 ? kernHalf : kern, dim3(grid), dim3(RT_WAVE), stackBytes, p == 0 ? ctx->stream : ctx->sideStream, a);
+        if (probe) { hipEventRecord(probe->stop, ctx->stream); probe->live = true; }
         HIP_TRY(ctx, hipGetLastError()); /* a refused launch ran no wave: the device counter did not move */
         /* every tile not taken by blockIdx is one successful fetch, and each of the grid waves overshoots once */
         ctx->tileQueueNext[p] += (unsigned long long)items + (a.queueStart ? (unsigned long long)grid : 0ull);

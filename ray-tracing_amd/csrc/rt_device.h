@@ -132,6 +132,7 @@ struct KArgs {
     float rcpWm1, rcpHm1;        /* 1 / (Resolution - 1)  — RCC:15 */
     float rcpW;                  /* 1 / numPixels.x       — RC:567,572 */
     float rcpSpp;                /* 1 / NumRaysPerPixel   — RC:581 */
+    int32_t suspendNum;          /* traverse() is left once active <= entered * suspendNum / 8 lanes are still traversing */
     int32_t raygenNoDefocus;     /* defocusStrength == 0, camera matrix finite, no component of the camera origin is -0 */
     /* counters: RT_COUNTER_SLOTS x RT_COUNTER_FIELDS u64 */
     unsigned long long* counters;

@@ -455,7 +455,7 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
     const DModel* __restrict__ models = a.models;
     const DPair* __restrict__ pairs = a.pairs;
     const DTri* __restrict__ tris = a.tris;
-    const int enteredNum = SUSPEND ? __popcll(__ballot(1)) * RT_SUSPEND_NUM : 0;
+    const int enteredNum = SUSPEND ? __popcll(__ballot(1)) * a.suspendNum : 0; /* a.suspendNum / RT_SUSPEND_DEN: 3/8 unless the launch tuner found 4/8 faster for this scene */
     phase_mark<STATS>(st, PH_TRAVERSE_CALL);
     /* One kind of work per iteration, chosen for the whole wave: the kind most lanes are
      * waiting for (wave-uniform branch, so only that code is issued).  A lane deep inside

@@ -400,6 +400,16 @@ def test_persistent_grid_size_does_not_change_results(pkg, api, orc, grid, monke
     assert [ca[k] for k in KEYS] == [cb[k] for k in KEYS]
 
 
+@pytest.mark.parametrize("suspend", ["2", "4", "6"])
+def test_suspension_threshold_does_not_change_results(pkg, api, orc, suspend, monkeypatch):
+    """The launch tuner switches the traversal loop's suspension threshold between 3/8 and 4/8 of the entrants
+    (RT_SUSPEND pins it): scheduling only — same bits and exact counters as the oracle for any value."""
+    monkeypatch.setenv("RT_SUSPEND", suspend)
+    a, b, ca, cb = pair(pkg, api, orc, 3, 96, 54, 3)
+    assert bits_equal(a, b)
+    assert [ca[k] for k in KEYS] == [cb[k] for k in KEYS]
+
+
 @pytest.mark.parametrize("coalesce", ["0", "1"])
 def test_held_back_frames_see_the_state_they_were_requested_with(pkg, api, orc, coalesce, monkeypatch):
     """rt_render_frame holds frames requested while the GPU is busy back and launches them fused.  Every call that
