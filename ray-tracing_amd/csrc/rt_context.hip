@@ -96,6 +96,7 @@ struct RtContext {
     bool verbose = false;
     /* rt_render_frame calls that arrive while earlier frames are still executing are held back (at most
      * RT_MAX_FUSED_FRAMES) and leave as ONE fused launch at the next call that needs them (flush_pending) */
+    int frameGroupOverride = 0; /* RT_FRAME_GROUP: frames per (tile, frame group) item of fused launches (tuning hook) */
     bool coalesce = true;  /* RT_COALESCE=0: every rt_render_frame launches at once */
     int pending = 0;       /* frames [frame - pending, frame) requested but not launched yet */
     bool fuseFrames = true; /* rt_render_frames(n): up to RT_MAX_FUSED_FRAMES frames per launch (RT_FUSE_FRAMES=0: one launch per frame) */
@@ -280,6 +281,7 @@ int rt_create(int device_id, RtContext** out)
     if (const char* l = getenv("RT_LPT")) ctx->lptEnabled = atoi(l) != 0;
     if (const char* t = getenv("RT_TWO_STREAMS")) ctx->twoStreams = atoi(t) != 0;
     if (const char* c = getenv("RT_COALESCE")) ctx->coalesce = atoi(c) != 0;
+    if (const char* fg = getenv("RT_FRAME_GROUP")) ctx->frameGroupOverride = atoi(fg);
     *out = ctx;
     return RT_OK;
 }
@@ -1210,7 +1212,21 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
     }
     for (int p = 0; p < parts; p++) {
         const int partTiles = (tiles - p + parts - 1) / parts;
-        const long long items = (long long)partTiles * (staged ? nFrames : 1);
+        /* frames per item: 1 = the most items and the shortest tail.  The FLAT scenes' per-frame chains are short and
+         * uniform; there one pixel set-up per group of frames is worth 7 % (config 2: 0.765 -> 0.710 ms/frame at groups
+         * of 4) as long as every resident wave still gets >= 8 items; fewer items than that, or groups of 8+, lose it to the
+         * tail again, and the BVH scenes gain nothing measurable (profiles/r02_frame_group_sweep.txt). */
+        int group = 1;
+        if (staged && ctx->flatScene) { /* the BVH kernel variants are compiled without groups */
+            if (ctx->frameGroupOverride > 0) group = ctx->frameGroupOverride;
+            else
+                while (group < 4 && 2 * group <= nFrames
+                       && (long long)partTiles * ((nFrames + 2 * group - 1) / (2 * group)) >= 8 * resident) group *= 2;
+            if (group > nFrames) group = nFrames;
+        }
+        a.frameGroup = group;
+        a.frameGroups = staged ? (nFrames + group - 1) / group : 1;
+        const long long items = (long long)partTiles * a.frameGroups;
         int grid = (int)(resident < items ? resident : items);
         if (ctx->gridOverride > 0) grid = (int)(ctx->gridOverride < items ? ctx->gridOverride : items);
         a.launchTiles = partTiles;

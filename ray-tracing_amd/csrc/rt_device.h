@@ -140,7 +140,9 @@ struct KArgs {
      * q*orderStride + orderOffset of the tile order.  Positions beyond the grid come from a global
      * atomic counter (monotonic across launches; this launch's positions start at tileQueueBase) */
     int32_t launchTiles, orderOffset, orderStride;
-    int32_t launchItems;         /* queue positions of this launch: launchTiles, or launchTiles * nFrames (tile, frame) items */
+    int32_t launchItems;         /* queue positions of this launch: launchTiles, or launchTiles * frameGroups (tile, frame group) items */
+    int32_t frameGroup;          /* consecutive frames per item (>= 1) */
+    int32_t frameGroups;         /* ceil(nFrames / frameGroup) */
     float* staging;              /* nFrames > 1: [frame - frame0][stagingStride pixels] RGBA colours awaiting rt_accumulate_kernel */
     uint32_t stagingStride;
     int32_t queueStart;          /* 1: the first position of every wave comes from the queue too (not blockIdx) */

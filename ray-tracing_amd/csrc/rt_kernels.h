@@ -723,12 +723,14 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
     /* A launch of nFrames > 1 frames hands out (tile, frame) items — queue position q = tile position q / nFrames, frame
      * q % nFrames — and a pixel's per-frame colours go to a staging slab that rt_accumulate_kernel adds up in frame order
      * afterwards: the frames of one pixel are independent chains (each reseeds from Frame, RC:552), only their SUM has an
-     * order, so a launch is no longer as long as nFrames chains of its slowest pixel. */
+     * order, so a launch is no longer as long as nFrames chains of its slowest pixel.  An item may cover a GROUP of
+     * frameGroup consecutive frames, which its lane runs back to back (one pixel set-up per group instead of per frame):
+     * the host picks the group size (1 when the items have to be many, more when the per-frame chains are short). */
 #define RT_ITEM(c, q, tilePos)                                  \
     do {                                                        \
         if ((c).nFrames > 1) {                                  \
-            tilePos = (q) / (c).nFrames;                        \
-            poolFrame = (c).frame0 + ((q) - tilePos * (c).nFrames); \
+            tilePos = (q) / (c).frameGroups;                    \
+            poolFrame = (c).frame0 + ((q) - tilePos * (c).frameGroups) * (c).frameGroup; \
         } else {                                                \
             tilePos = (q);                                      \
             poolFrame = (c).frame0;                             \
@@ -890,12 +892,25 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                             *reinterpret_cast<float4*>(c.accumulated + pixOff) = acc;
                         }
                     }
-                    laneDone = true;
-                    if (c.tileCost) { /* longest serial chain of this tile's pixels: the next launches' queue order */
-                        const uint32_t prow = pixLinear / c.W, pcol = pixLinear - prow * c.W;
-                        uint32_t* const slot = c.tileCost + (prow >> 3) * (uint32_t)c.tilesX + (pcol >> 3);
-                        const uint32_t chain = segments - PXU(PX_SEGSTART);
-                        if (chain > *slot) atomicMax(slot, chain); /* the plain read may be stale (lower): then the atomic decides */
+                    const int nextFrame = (int)PXU(PX_FRAME) + 1;
+                    /* the item ends at a multiple of frameGroup past frame0, or with the launch (once per pixel and frame:
+                     * the integer division costs nothing next to the frame's segments, an LDS field would cost occupancy) */
+                    /* groups exist in the FLAT variant only (the host keeps frameGroup at 1 otherwise): the BVH variants are
+                     * register-bound and paid 1.3 % for carrying the branch without ever gaining from it */
+                    if (!FLAT || nextFrame >= c.frame0 + c.nFrames || (uint32_t)(nextFrame - c.frame0) % (uint32_t)c.frameGroup == 0u) {
+                        laneDone = true;
+                        if (c.tileCost) { /* longest serial chain (per frame) of this tile's pixels: the next launches' queue order */
+                            const uint32_t prow = pixLinear / c.W, pcol = pixLinear - prow * c.W;
+                            uint32_t* const slot = c.tileCost + (prow >> 3) * (uint32_t)c.tilesX + (pcol >> 3);
+                            const uint32_t chain = FLAT ? (segments - PXU(PX_SEGSTART)) / (uint32_t)c.frameGroup : segments - PXU(PX_SEGSTART);
+                            if (chain > *slot) atomicMax(slot, chain); /* the plain read may be stale (lower): then the atomic decides */
+                        }
+                    } else { /* the next frame of this item's group: same pixel, fresh seed (RC:552) */
+                        rng = PXU(PX_INDEX) + (uint32_t)nextFrame * 719393u + (uint32_t)c.seed;
+                        sample = 0;
+                        PXU(PX_FRAME) = (uint32_t)nextFrame;
+                        PXU(PX_SAMPLE) = 0;
+                        PXF(PX_TIX) = 0.0f; PXF(PX_TIY) = 0.0f; PXF(PX_TIZ) = 0.0f;
                     }
                 }
                 if (!laneDone && sample < c.spp) {

@@ -410,6 +410,33 @@ def test_suspension_threshold_does_not_change_results(pkg, api, orc, suspend, mo
     assert [ca[k] for k in KEYS] == [cb[k] for k in KEYS]
 
 
+def test_frame_group_size_does_not_change_a_bit(pkg, api, monkeypatch):
+    """Fused launches hand out (tile, group of g frames) items; g is a tuning choice of the host (RT_FRAME_GROUP pins
+    it, incl. sizes that do not divide the frame count) and never moves a bit or a counter."""
+    ref = {}
+    for grp in ("1", "3", "4", "16", ""):
+        if grp:
+            monkeypatch.setenv("RT_FRAME_GROUP", grp)
+        else:
+            monkeypatch.delenv("RT_FRAME_GROUP", raising=False)
+        for cfg, nfr in ((2, 11), (3, 16)):
+            tr = api.create_tracer(0)
+            tr.enable_stats(True)
+            sc = pkg.scenes.get(cfg)
+            mgr = sc.make_manager(tr, api, 256, 144)
+            mgr.OnEnable(renderSeed=4)
+            mgr.RenderFrames(nfr)
+            mgr.RenderFrames(5)
+            out = (tr.read_accumulated().copy(), tr.read_frame().copy(), tr.counters()["segments"])
+            tr.close()
+            if cfg not in ref:
+                ref[cfg] = out
+            else:
+                assert np.array_equal(out[0].view(np.uint32), ref[cfg][0].view(np.uint32)), (grp, cfg)
+                assert np.array_equal(out[1].view(np.uint32), ref[cfg][1].view(np.uint32)), (grp, cfg)
+                assert out[2] == ref[cfg][2]
+
+
 @pytest.mark.parametrize("coalesce", ["0", "1"])
 def test_held_back_frames_see_the_state_they_were_requested_with(pkg, api, orc, coalesce, monkeypatch):
     """rt_render_frame holds frames requested while the GPU is busy back and launches them fused.  Every call that
