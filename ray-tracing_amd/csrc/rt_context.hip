@@ -96,6 +96,8 @@ struct RtContext {
     bool verbose = false;
     /* rt_render_frame calls that arrive while earlier frames are still executing are held back (at most
      * RT_MAX_FUSED_FRAMES) and leave as ONE fused launch at the next call that needs them (flush_pending) */
+    void* dPxCold = nullptr; /* pixel records of the resident waves: 2 launch slots (main / side stream) x pxColdWaves x 2 KB */
+    long long pxColdWaves = 0;
     int frameGroupOverride = 0; /* RT_FRAME_GROUP: frames per (tile, frame group) item of fused launches (tuning hook) */
     bool coalesce = true;  /* RT_COALESCE=0: every rt_render_frame launches at once */
     int pending = 0;       /* frames [frame - pending, frame) requested but not launched yet */
@@ -317,6 +319,7 @@ void rt_destroy(RtContext* ctx)
     hipFree(ctx->dTileOrder);
     hipFree(ctx->dDisplay);
     hipFree(ctx->dStaging);
+    hipFree(ctx->dPxCold);
     for (auto& pr : ctx->tuner.probe) {
         if (pr.start) hipEventDestroy(pr.start);
         if (pr.stop) hipEventDestroy(pr.stop);
@@ -1116,8 +1119,19 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, RT_WAVE, stackBytes));
         ctx->occPerCU[variant] = perCU > 0 ? perCU : 1;
         ctx->occBytes[variant] = stackBytes + 1;
+        if (getenv("RT_DEBUG_LAUNCH"))
+            fprintf(stderr, "[rt] kernel variant %d: %d stack entries, %zu B of LDS per wave, %d waves per CU\n", variant, ctx->stackEntries, stackBytes, perCU);
     }
     const long long resident = (long long)ctx->occPerCU[variant] * ctx->numCUs;
+    {
+        const long long waves = ctx->gridOverride > resident ? ctx->gridOverride : resident;
+        if (ctx->pxColdWaves < waves) { /* kernels in flight use the old block: it is freed stream-ordered, not now */
+            HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
+            hipFree(ctx->dPxCold); ctx->dPxCold = nullptr; ctx->pxColdWaves = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dPxCold, (size_t)2 * waves * RT_WAVE * 2 * sizeof(float4)));
+            ctx->pxColdWaves = waves;
+        }
+    }
     /* longest-chain-first queue order, learnt from the frames already rendered at this size */
     if (ctx->lptEnabled && ctx->orderTiles != tiles) {
         hipFree(ctx->dTileCost); ctx->dTileCost = nullptr;
@@ -1229,6 +1243,7 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         const long long items = (long long)partTiles * a.frameGroups;
         int grid = (int)(resident < items ? resident : items);
         if (ctx->gridOverride > 0) grid = (int)(ctx->gridOverride < items ? ctx->gridOverride : items);
+        a.pxCold = (float4*)ctx->dPxCold + (size_t)p * ctx->pxColdWaves * RT_WAVE * 2;
         a.launchTiles = partTiles;
         a.launchItems = (int)items;
         a.orderOffset = p;

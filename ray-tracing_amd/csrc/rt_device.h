@@ -29,7 +29,7 @@
 #define RT_WAVE 64
 #define RT_STACK_DEPTH 34            /* >= RT_MAX_BVH_DEPTH + 2 */
 #define RT_COUNTER_SLOTS 1024        /* counters are spread over slots to avoid same-address atomics */
-#define RT_PIXEL_FIELDS 11
+#define RT_PIXEL_FIELDS 4
 #define RT_N_PHASES 12
 #define RT_COUNTER_FIELDS (8 + 2 * RT_N_PHASES)
 
@@ -141,6 +141,7 @@ struct KArgs {
      * atomic counter (monotonic across launches; this launch's positions start at tileQueueBase) */
     int32_t launchTiles, orderOffset, orderStride;
     int32_t launchItems;         /* queue positions of this launch: launchTiles, or launchTiles * frameGroups (tile, frame group) items */
+    float4* pxCold;              /* per-wave pixel records of this launch: [grid][64 lanes][2] float4 (rt_kernels.h, PX_COLD) */
     int32_t frameGroup;          /* consecutive frames per item (>= 1) */
     int32_t frameGroups;         /* ceil(nFrames / frameGroup) */
     float* staging;              /* nFrames > 1: [frame - frame0][stagingStride pixels] RGBA colours awaiting rt_accumulate_kernel */

@@ -40,9 +40,14 @@
 #define RT_SUSPEND_NUM 3
 #define RT_SUSPEND_DEN 8
 #endif
-/* waves per SIMD the register allocator must leave room for (launch_bounds 2nd argument) */
+/* waves per SIMD the register allocator must leave room for (launch_bounds 2nd argument).  Built without the SLP
+ * vectoriser (Makefile) the BVH variants need 83 VGPRs: 6 waves = 80 VGPRs costs no spill and is worth 2–7 % per frame
+ * (7 waves: 30 spilled dwords, slower); the FLAT variant fits 8 waves = 64 VGPRs (−9 % on config 2). */
 #ifndef RT_MIN_WAVES_PER_SIMD
-#define RT_MIN_WAVES_PER_SIMD 5
+#define RT_MIN_WAVES_PER_SIMD 6
+#endif
+#ifndef RT_MIN_WAVES_PER_SIMD_FLAT
+#define RT_MIN_WAVES_PER_SIMD_FLAT 8
 #endif
 /* inner steps per vote won by phase B (lanes that reach a leaf or run out wait for the next vote) */
 #ifndef RT_INNER_BURST
@@ -779,7 +784,12 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
     uint32_t* const pxu = &s_stack[(size_t)cold_args().stackEntries * RT_WAVE + lane];
     uint32_t* const extBase = pxu + RT_PIXEL_FIELDS * RT_WAVE; /* candidate-mask extension, scenes with more than 64 models */
     float* const pxf = reinterpret_cast<float*>(pxu);
-    enum { PX_INDEX = 0, PX_LINEAR, PX_SEGSTART, PX_FRAME, PX_SAMPLE, PX_FPX, PX_FPY, PX_FPZ, PX_TIX, PX_TIY, PX_TIZ };
+    enum { PX_SAMPLE = 0, PX_TIX, PX_TIY, PX_TIZ };
+    /* What is written once per pixel and read once per sample or per frame lives in a per-wave record in device memory
+     * (two float4 per lane, coalesced, private to the lane that wrote them): LDS decides how many waves a CU holds
+     * (stack + pixel fields: 160 KB / 6 waves per SIMD = 26 rows of 256 B), and every wave counts (§4.14).
+     *   q[0] = (focus point xyz, pixelIndex)   q[1] = (linear pixel index, segment count at set-up, frame, -) */
+#define PX_COLD(c) ((c).pxCold + ((size_t)blockIdx.x * RT_WAVE + (size_t)lane) * 2)
 #define PXU(k) pxu[(k) * RT_WAVE]
 #define PXF(k) pxf[(k) * RT_WAVE]
     uint32_t rng = 0;
@@ -847,12 +857,12 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     float cam[16];
                     for (int k = 0; k < 16; k++) cam[k] = c.cam[k];
                     const rt_f3 focusPoint = rt_mul_point(cam, fpl, 1.0f);
-                    PXU(PX_INDEX) = pixelIndex;
-                    PXU(PX_LINEAR) = (uint32_t)lrow * c.W + (uint32_t)x;
-                    PXU(PX_SEGSTART) = segments;
-                    PXU(PX_FRAME) = (uint32_t)poolFrame;
+                    {
+                        float4* const cold = PX_COLD(c);
+                        cold[0] = make_float4(focusPoint.x, focusPoint.y, focusPoint.z, __uint_as_float(pixelIndex));
+                        cold[1] = make_float4(__uint_as_float((uint32_t)lrow * c.W + (uint32_t)x), __uint_as_float(segments), __uint_as_float((uint32_t)poolFrame), 0.0f);
+                    }
                     PXU(PX_SAMPLE) = 0;
-                    PXF(PX_FPX) = focusPoint.x; PXF(PX_FPY) = focusPoint.y; PXF(PX_FPZ) = focusPoint.z;
                     PXF(PX_TIX) = 0.0f; PXF(PX_TIY) = 0.0f; PXF(PX_TIZ) = 0.0f;
                     rng = pixelIndex + (uint32_t)poolFrame * 719393u + (uint32_t)c.seed; /* RC:552 */
                     pathActive = false;
@@ -873,13 +883,16 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                 int sample = (int)PXU(PX_SAMPLE);
                 if (sample == c.spp) {
                     /* RC:581 + RCC:18-23: finish this frame of this pixel */
-                    const uint32_t pixLinear = PXU(PX_LINEAR);
+                    float4* const cold = PX_COLD(c);
+                    const float4 rec = cold[1];
+                    const uint32_t pixLinear = __float_as_uint(rec.x), segStart = __float_as_uint(rec.y);
+                    const int frameNow = (int)__float_as_uint(rec.z);
                     const size_t pixOff = (size_t)pixLinear * 4;
                     rt_f3 col = rt_v3(PXF(PX_TIX), PXF(PX_TIY), PXF(PX_TIZ)) * c.rcpSpp; /* / NumRaysPerPixel */
                     if (c.nFrames > 1) {
                         /* one of several frames of this launch: the colour waits in its frame's slab for
                          * rt_accumulate_kernel, which performs RCC:18-23 for the frames in order */
-                        const size_t slab = (size_t)((int)PXU(PX_FRAME) - c.frame0) * c.stagingStride;
+                        const size_t slab = (size_t)(frameNow - c.frame0) * c.stagingStride;
                         *reinterpret_cast<float4*>(c.staging + (slab + pixLinear) * 4) = make_float4(col.x, col.y, col.z, 1.0f);
                     } else {
                         *reinterpret_cast<float4*>(c.frameRender + pixOff) = make_float4(col.x, col.y, col.z, 1.0f);
@@ -892,7 +905,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                             *reinterpret_cast<float4*>(c.accumulated + pixOff) = acc;
                         }
                     }
-                    const int nextFrame = (int)PXU(PX_FRAME) + 1;
+                    const int nextFrame = frameNow + 1;
                     /* the item ends at a multiple of frameGroup past frame0, or with the launch (once per pixel and frame:
                      * the integer division costs nothing next to the frame's segments, an LDS field would cost occupancy) */
                     /* groups exist in the FLAT variant only (the host keeps frameGroup at 1 otherwise): the BVH variants are
@@ -902,13 +915,13 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                         if (c.tileCost) { /* longest serial chain (per frame) of this tile's pixels: the next launches' queue order */
                             const uint32_t prow = pixLinear / c.W, pcol = pixLinear - prow * c.W;
                             uint32_t* const slot = c.tileCost + (prow >> 3) * (uint32_t)c.tilesX + (pcol >> 3);
-                            const uint32_t chain = FLAT ? (segments - PXU(PX_SEGSTART)) / (uint32_t)c.frameGroup : segments - PXU(PX_SEGSTART);
+                            const uint32_t chain = FLAT ? (segments - segStart) / (uint32_t)c.frameGroup : segments - segStart;
                             if (chain > *slot) atomicMax(slot, chain); /* the plain read may be stale (lower): then the atomic decides */
                         }
                     } else { /* the next frame of this item's group: same pixel, fresh seed (RC:552) */
-                        rng = PXU(PX_INDEX) + (uint32_t)nextFrame * 719393u + (uint32_t)c.seed;
+                        rng = __float_as_uint(cold[0].w) + (uint32_t)nextFrame * 719393u + (uint32_t)c.seed;
                         sample = 0;
-                        PXU(PX_FRAME) = (uint32_t)nextFrame;
+                        cold[1].z = __uint_as_float((uint32_t)nextFrame);
                         PXU(PX_SAMPLE) = 0;
                         PXF(PX_TIX) = 0.0f; PXF(PX_TIY) = 0.0f; PXF(PX_TIZ) = 0.0f;
                     }
@@ -937,7 +950,8 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                         rayOrigin = camOrigin + camRight * (dj.x * c.defocus * invNumPixelsX) + camUp * (dj.y * c.defocus * invNumPixelsX);
                     }
                     rt_f2 jj = rand_circle(&rng);
-                    const rt_f3 focusPoint = rt_v3(PXF(PX_FPX), PXF(PX_FPY), PXF(PX_FPZ));
+                    const float4 fp4 = PX_COLD(c)[0];
+                    const rt_f3 focusPoint = rt_v3(fp4.x, fp4.y, fp4.z);
                     rt_f3 jfp = focusPoint + camRight * (jj.x * c.diverge * invNumPixelsX) + camUp * (jj.y * c.diverge * invNumPixelsX);
                     rpos = rayOrigin;
                     rdir = rt_normalize(jfp - rayOrigin);
@@ -1038,6 +1052,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
 #undef RT_SET_POOL
 #undef PXU
 #undef PXF
+#undef PX_COLD
     /* exact work counters: one set of atomics per wave, spread over slots */
     uint32_t segSum = wave_sum(segments);
     unsigned long long* slot = a.counters + (size_t)(blockIdx.x % RT_COUNTER_SLOTS) * RT_COUNTER_FIELDS;
@@ -1075,12 +1090,12 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
 /* MANY: scenes with more than 64 models (two-level filter, candidate masks extended into LDS) — a separate
  * instantiation so that the common case keeps its registers */
 template <bool STATS, bool FLAT, bool MANY = false>
-__global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_kernel(const KArgs a)
+__global__ void __launch_bounds__(RT_WAVE, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : RT_MIN_WAVES_PER_SIMD) rt_trace_kernel(const KArgs a)
 {
     trace_body<STATS, FLAT, MANY>(a);
 }
 template <bool STATS, bool FLAT, bool MANY = false>
-__global__ void __launch_bounds__(RT_WAVE, RT_MIN_WAVES_PER_SIMD) rt_trace_half_kernel(const KArgs a)
+__global__ void __launch_bounds__(RT_WAVE, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : RT_MIN_WAVES_PER_SIMD) rt_trace_half_kernel(const KArgs a)
 {
     trace_body<STATS, FLAT, MANY>(a);
 }
