@@ -786,10 +786,10 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
     float* const pxf = reinterpret_cast<float*>(pxu);
     enum { PX_SAMPLE = 0, PX_TIX, PX_TIY, PX_TIZ };
     /* What is written once per pixel and read once per sample or per frame lives in a per-wave record in device memory
-     * (two float4 per lane, coalesced, private to the lane that wrote them): LDS decides how many waves a CU holds
+     * (two float4 per lane, [2][64] per wave, private to the lane that wrote them): LDS decides how many waves a CU holds
      * (stack + pixel fields: 160 KB / 6 waves per SIMD = 26 rows of 256 B), and every wave counts (§4.14).
      *   q[0] = (focus point xyz, pixelIndex)   q[1] = (linear pixel index, segment count at set-up, frame, -) */
-#define PX_COLD(c) ((c).pxCold + ((size_t)blockIdx.x * RT_WAVE + (size_t)lane) * 2)
+#define PX_COLD(c) ((c).pxCold + (size_t)blockIdx.x * (2 * RT_WAVE) + (size_t)lane) /* [wave][2][lane]: a wave's store covers 1 KB without gaps */
 #define PXU(k) pxu[(k) * RT_WAVE]
 #define PXF(k) pxf[(k) * RT_WAVE]
     uint32_t rng = 0;
@@ -860,7 +860,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     {
                         float4* const cold = PX_COLD(c);
                         cold[0] = make_float4(focusPoint.x, focusPoint.y, focusPoint.z, __uint_as_float(pixelIndex));
-                        cold[1] = make_float4(__uint_as_float((uint32_t)lrow * c.W + (uint32_t)x), __uint_as_float(segments), __uint_as_float((uint32_t)poolFrame), 0.0f);
+                        cold[RT_WAVE] = make_float4(__uint_as_float((uint32_t)lrow * c.W + (uint32_t)x), __uint_as_float(segments), __uint_as_float((uint32_t)poolFrame), 0.0f);
                     }
                     PXU(PX_SAMPLE) = 0;
                     PXF(PX_TIX) = 0.0f; PXF(PX_TIY) = 0.0f; PXF(PX_TIZ) = 0.0f;
@@ -884,7 +884,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                 if (sample == c.spp) {
                     /* RC:581 + RCC:18-23: finish this frame of this pixel */
                     float4* const cold = PX_COLD(c);
-                    const float4 rec = cold[1];
+                    const float4 rec = cold[RT_WAVE];
                     const uint32_t pixLinear = __float_as_uint(rec.x), segStart = __float_as_uint(rec.y);
                     const int frameNow = (int)__float_as_uint(rec.z);
                     const size_t pixOff = (size_t)pixLinear * 4;
@@ -921,7 +921,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     } else { /* the next frame of this item's group: same pixel, fresh seed (RC:552) */
                         rng = __float_as_uint(cold[0].w) + (uint32_t)nextFrame * 719393u + (uint32_t)c.seed;
                         sample = 0;
-                        cold[1].z = __uint_as_float((uint32_t)nextFrame);
+                        cold[RT_WAVE].z = __uint_as_float((uint32_t)nextFrame);
                         PXU(PX_SAMPLE) = 0;
                         PXF(PX_TIX) = 0.0f; PXF(PX_TIY) = 0.0f; PXF(PX_TIZ) = 0.0f;
                     }
