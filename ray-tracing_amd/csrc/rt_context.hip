@@ -1231,7 +1231,7 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
          * of 4) as long as every resident wave still gets >= 8 items; fewer items than that, or groups of 8+, lose it to the
          * tail again, and the BVH scenes gain nothing measurable (profiles/r02_frame_group_sweep.txt). */
         int group = 1;
-        if (staged && ctx->flatScene) { /* the BVH kernel variants are compiled without groups */
+        if (staged && ctx->flatScene && ctx->params.numRaysPerPixel < 65536) { /* the BVH kernel variants are compiled without groups */
             if (ctx->frameGroupOverride > 0) group = ctx->frameGroupOverride;
             else
                 while (group < 4 && 2 * group <= nFrames

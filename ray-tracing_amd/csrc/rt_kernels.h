@@ -880,13 +880,18 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
         if (!inTrav) {
             if (!pathActive) {
                 const RT_CAS KArgs& c = cold_args();
-                int sample = (int)PXU(PX_SAMPLE);
+                /* FLAT items that cover a group of frames keep the frame's offset within the record's first frame in the
+                 * upper half of the sample word (the host only forms groups when spp fits the lower half) */
+                const uint32_t sampleWord = PXU(PX_SAMPLE);
+                const bool grouped = FLAT && c.frameGroup > 1;
+                int sample = grouped ? (int)(sampleWord & 0xffffu) : (int)sampleWord;
                 if (sample == c.spp) {
                     /* RC:581 + RCC:18-23: finish this frame of this pixel */
                     float4* const cold = PX_COLD(c);
                     const float4 rec = cold[RT_WAVE];
                     const uint32_t pixLinear = __float_as_uint(rec.x), segStart = __float_as_uint(rec.y);
-                    const int frameNow = (int)__float_as_uint(rec.z);
+                    const int frameFirst = (int)__float_as_uint(rec.z);
+                    const int frameNow = frameFirst + (grouped ? (int)(sampleWord >> 16) : 0);
                     const size_t pixOff = (size_t)pixLinear * 4;
                     rt_f3 col = rt_v3(PXF(PX_TIX), PXF(PX_TIY), PXF(PX_TIZ)) * c.rcpSpp; /* / NumRaysPerPixel */
                     if (c.nFrames > 1) {
@@ -921,8 +926,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     } else { /* the next frame of this item's group: same pixel, fresh seed (RC:552) */
                         rng = __float_as_uint(cold[0].w) + (uint32_t)nextFrame * 719393u + (uint32_t)c.seed;
                         sample = 0;
-                        cold[RT_WAVE].z = __uint_as_float((uint32_t)nextFrame);
-                        PXU(PX_SAMPLE) = 0;
+                        PXU(PX_SAMPLE) = (uint32_t)(nextFrame - frameFirst) << 16;
                         PXF(PX_TIX) = 0.0f; PXF(PX_TIY) = 0.0f; PXF(PX_TIZ) = 0.0f;
                     }
                 }
@@ -958,7 +962,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     transmittance = rt_v3s(1.0f);
                     pathLight = rt_v3s(0.0f);
                     bounce = 0;
-                    PXU(PX_SAMPLE) = (uint32_t)(sample + 1);
+                    PXU(PX_SAMPLE) = grouped ? (PXU(PX_SAMPLE) & 0xffff0000u) | (uint32_t)(sample + 1) : (uint32_t)(sample + 1);
                     if (c.maxBounce >= 0) pathActive = true;                /* RC:485: the loop runs for i = 0 */
                     else { PXF(PX_TIX) = PXF(PX_TIX) + 0.0f; PXF(PX_TIY) = PXF(PX_TIY) + 0.0f; PXF(PX_TIZ) = PXF(PX_TIZ) + 0.0f; } /* Trace returned 0 (RC:578) */
                 }
