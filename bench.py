@@ -274,7 +274,7 @@ def valu_roofline(pmc, launch_ms, segments_per_launch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=65, help="timed frames (default 65: a progressive render's steady state = the first frame at once + 4 coalesced launches of 16)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, help="scene id (default 2 = the headline workload; 5 = the 8-GPU 3840x2160 case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
