@@ -532,5 +532,22 @@ def main():
         dist.destroy_process_group()
 
 
+def run():
+    """main() with every failure tagged by rank on stderr (a launcher shows only the tail of one rank's output)."""
+    rank = os.environ.get("RANK", "0")
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001 - report, then fail the process
+        import traceback
+        sys.stderr.write(f"[rank {rank}] bench.py failed: {type(e).__name__}: {e}\n")
+        for line in traceback.format_exc().splitlines():
+            sys.stderr.write(f"[rank {rank}] {line}\n")
+        sys.stderr.flush()
+        # a rank that leaves while its peers wait in a collective must not hang on interpreter teardown
+        os._exit(1)
+
+
 if __name__ == "__main__":
-    main()
+    run()
