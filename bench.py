@@ -141,6 +141,31 @@ def parity_check(pkg, api, dev_index, scene_id, width, height, strips):
             "bit_identical": ident, "rel_l2_per_channel": l2, "max_rel_err": mx}
 
 
+def oracle_strips_check(pkg, scene_id, width, height, image, frames, strips):
+    """`image` (H, W, 4: an accumulation buffer after `frames` frames from a reset, renderSeed 1) against the CPU oracle on
+    the given 8-row strips: bitwise + per-channel relative L2."""
+    import numpy as np
+    orc = graft.load_oracle()
+    c = orc.create_tracer(min(os.cpu_count() or 1, 16))
+    m2 = pkg.scenes.get(scene_id).make_manager(c, orc, width, height)
+    m2.OnEnable(renderSeed=1)
+    for f in range(frames):
+        for s in strips:
+            m2.numAccumulatedFrames = 1 + f
+            m2.SetShaderParams()
+            orc.set_row_window(c.h, s * 8, min(height, s * 8 + 8))
+            c.render_frame()
+    cpu = c.read_accumulated()
+    c.close()
+    rows = np.concatenate([np.arange(s * 8, min(height, s * 8 + 8)) for s in strips])
+    a, b = np.ascontiguousarray(image[rows]), np.ascontiguousarray(cpu[rows])
+    ident = bool(np.array_equal(a.view(np.uint32), b.view(np.uint32)))
+    l2 = [float(np.sqrt(np.sum((a[..., k].astype(np.float64) - b[..., k]) ** 2) / max(float(np.sum(b[..., k].astype(np.float64) ** 2)), 1e-300)))
+          for k in range(3)]
+    return {"what": f"frames 1..{frames} from a reset at {width}x{height}, 8-row strips {list(strips)} of the GATHERED image vs oracle/ "
+                    f"({len(rows) * width} pixels)", "bit_identical": ident, "rel_l2_per_channel": l2}
+
+
 # --------------------------------------------------------------------------- PMC passes (rocprofv3 around a child run)
 def pmc_child(args):
     """Child of the PMC passes: one kernel per frame on one stream, `steps` frames, nothing else (no torch)."""
@@ -333,6 +358,8 @@ def main():
         tiled.bind(W, H)
         tracer.reset_accumulation()
     n_models, n_spheres = len(scene.models), len(scene.spheres)
+    diagnostics = []          # failures of the informational passes: reported in the line, never fatal, never skipping a collective
+    accumulated = [0]         # frames added into the accumulation buffer since its last reset (every pass below adds K)
 
     def barrier():
         if world > 1:
@@ -340,9 +367,15 @@ def main():
         tracer.synchronize()
         torch.cuda.synchronize()
 
+    def replay_from(frame):
+        """Point the mirror (and the library) back at `frame`: the next frames rendered are frame, frame+1, ..."""
+        mgr.numAccumulatedFrames = frame
+        mgr.SetShaderParams()
+
     # ---- warmup
     for _ in range(args.warmup):
         mgr.RenderFrame()
+    accumulated[0] += args.warmup
     barrier()
     first_frame = tracer.frame()
 
@@ -356,6 +389,7 @@ def main():
     tracer.timer_end()
     barrier()
     t1 = time.perf_counter()
+    accumulated[0] += args.steps
     timed = tracer.counters()
     elapsed = t1 - t0
     segments = timed["segments"]
@@ -369,32 +403,35 @@ def main():
         mgr.RenderFrame()
     barrier()
     init_elapsed = time.perf_counter() - i0
+    accumulated[0] += args.steps
     init_segments = tracer.counters()["segments"]
-    assert init_segments == segments, (init_segments, segments)
+    if init_segments != segments:   # same frame indices, same seed: the exact counters must agree
+        diagnostics.append(f"rank {rank}: RenderFrame() pass counted {init_segments} segments, timed pass {segments}")
 
     # ---- untimed replay of the same K frames with the detailed counters on
     # (identical work: the frame index and seed decide every ray) -> algorithmic bytes
     tracer.reset_counters()
     tracer.enable_stats(True)
-    mgr.numAccumulatedFrames = first_frame
-    mgr.SetShaderParams()
+    replay_from(first_frame)
     tracer.render_frames(args.steps)
+    accumulated[0] += args.steps
     stats = tracer.counters()
     tracer.enable_stats(False)
-    assert stats["segments"] == segments, (stats["segments"], segments)
+    if stats["segments"] != segments:
+        diagnostics.append(f"rank {rank}: stats replay counted {stats['segments']} segments, timed pass {segments}")
 
     # ---- informational: the same K frames through the batched API (rt_render_frames: up to 16
-    # frames per launch, each pixel runs its frames back to back; identical final buffers)
+    # frames per launch as (tile, frame) items; identical final buffers)
     batched = None
     if not args.no_batched:
-        mgr.numAccumulatedFrames = first_frame
-        mgr.SetShaderParams()
+        replay_from(first_frame)
         tracer.reset_counters()
         barrier()
         b0 = time.perf_counter()
         tracer.render_frames(args.steps)
         barrier()
         batched_elapsed = time.perf_counter() - b0
+        accumulated[0] += args.steps
         batched = {"what": "rt_render_frames(K): frames fused up to 16 per launch (this rank)",
                    "value": tracer.counters()["segments"] / batched_elapsed / 1e6, "unit": "Mrays/s",
                    "ms_per_frame": batched_elapsed / args.steps * 1e3}
@@ -408,13 +445,17 @@ def main():
     fpl = max(1, min(16, args.steps))
     if rank == 0:
         part = (pkg.dist.STRIP_ROWS, rank, world) if tiled else None
-        launch_ms, launch_segments = launch_profile(pkg, api, dev_index, args.config, W, H, max(2, min(6, args.steps // fpl + 1)), fpl, part)
-        single_ms, seg1 = launch_profile(pkg, api, dev_index, args.config, W, H, min(args.steps, 8), 1, part)
+        try:
+            launch_ms, launch_segments = launch_profile(pkg, api, dev_index, args.config, W, H, max(2, min(6, args.steps // fpl + 1)), fpl, part)
+            single_ms, seg1 = launch_profile(pkg, api, dev_index, args.config, W, H, min(args.steps, 8), 1, part)
+        except Exception as e:  # informational
+            diagnostics.append(f"rank 0: launch_profile: {type(e).__name__}: {e}")
 
-    # ---- readback: the one collective of the multi-GPU path
+    # ---- readback: the one collective of the multi-GPU path (every rank takes part whatever happened above)
     gather_ms = None
     gather_error = None
     gather_alpha_ok = None
+    gathered = None
     if tiled:
         barrier()
         g0 = time.perf_counter()
@@ -424,11 +465,42 @@ def main():
             gather_ms = (time.perf_counter() - g0) * 1e3
             if rank == 0:
                 assert tuple(full.shape) == (H, W, 4)
-                gather_alpha_ok = bool((full[..., 3] == float(tracer.frame() - 1)).all().item())  # every pixel accumulated every frame
+                # alpha counts the additions (RCC:22 adds 1 per frame): every pixel of every rank's strips got every frame
+                alpha = full[..., 3]
+                gather_alpha_ok = bool((alpha == float(accumulated[0])).all().item())
+                gathered = {"alpha_expected": accumulated[0], "alpha_min": float(alpha.min().item()), "alpha_max": float(alpha.max().item())}
             del full
         except Exception as e:  # the timed result stands on its own; report the collective's failure instead of losing the line
             gather_ms = None
             gather_error = f"{type(e).__name__}: {e}"
+        # ---- and the gathered image itself against the oracle: a fresh progressive render of 2 frames on all ranks,
+        # gathered, sample strips (one per rank at least) re-rendered by the CPU oracle on rank 0
+        try:
+            mgr.ResetAccumulatedRender()
+            accumulated[0] = 0
+            mgr.RenderFrames(2)
+            accumulated[0] += 2
+            full = tiled.gather_accumulated(H, comm_device=comm_device)
+            if rank == 0:
+                n_strips = (H + 7) // 8
+                strips = sorted(set([r for r in range(min(world, n_strips))] + [n_strips // 2 + r for r in range(min(world, 3))] + [n_strips - 1]))
+                strips = [s_ for s_ in strips if 0 <= s_ < n_strips][:12]
+                gp = oracle_strips_check(pkg, args.config, W, H, full.cpu().numpy(), 2, strips)
+                gp["ranks_covered"] = sorted({s_ % world for s_ in strips})
+                gathered = dict(gathered or {}, parity_vs_oracle=gp)
+            del full
+        except Exception as e:
+            diagnostics.append(f"rank {rank}: gathered-image parity: {type(e).__name__}: {e}")
+
+    # ---- who took part: one record per rank, collected with the job's own backend (RCCL when N GPUs are there)
+    devices_seen = None
+    if world > 1:
+        props = torch.cuda.get_device_properties(dev_index)
+        me = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "name": props.name,
+              "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
+              "pci_device_id": getattr(props, "pci_device_id", None), "pid": os.getpid(), "backend": dist.get_backend()}
+        devices_seen = [None] * world
+        dist.all_gather_object(devices_seen, me)
 
     if world > 1:
         t = torch.tensor([elapsed, float(timed["gpuMs"]), init_elapsed], dtype=torch.float64, device=comm_device)
@@ -441,6 +513,12 @@ def main():
         kernel_ms_max = timed["gpuMs"]
         total_segments = float(segments)
         total_bytes = float(pkg.abi.algorithmic_bytes(stats, n_models, n_spheres))
+
+    diagnostics_all = diagnostics
+    if world > 1:
+        lists = [None] * world
+        dist.all_gather_object(lists, diagnostics)
+        diagnostics_all = [d_ for l_ in lists for d_ in l_]
 
     if rank == 0:
         my_bytes = pkg.abi.algorithmic_bytes(stats, n_models, n_spheres) / args.steps
@@ -489,6 +567,10 @@ def main():
             "value_with_initframe": total_segments / init_elapsed / 1e6,
             "ms_per_step_with_initframe": init_elapsed / args.steps * 1e3,
             "gather_ms": gather_ms, "gather_error": gather_error, "gathered_image_complete": gather_alpha_ok,
+            "gathered_image": gathered,
+            "ranks_seen": (dist.get_world_size() if world > 1 else 1), "devices_seen": devices_seen,
+            "distinct_devices": (len({(d_["uuid"], d_["pci_bus_id"]) for d_ in devices_seen}) if devices_seen else 1),
+            "diagnostics": diagnostics_all,
             "launches": ("K x rt_render_frame, back to back: the library starts an idle GPU at once (frame 1: 2 kernels on 2 streams, disjoint "
                          "tile halves) and holds frames requested while earlier ones still execute back, up to 16, to launch them fused as "
                          "(tile, frame) work items whose per-frame colours are added in frame order afterwards (same bits); "

@@ -46,25 +46,37 @@ def random_scene(pkg, seed):
 @pytest.mark.parametrize("seed", range(16))
 def test_random_scene_bit_exact(pkg, api, orc, seed):
     out = []
-    for lib, tr in ((api, api.create_tracer(0)), (orc, orc.create_tracer(8))):
+    for lib, tr, stats in _three(api, orc):
         sc, render_seed = random_scene(pkg, seed)
-        if lib is api:
+        if stats:
             tr.enable_stats(True)
         mgr = sc.make_manager(tr, lib)
         mgr.OnEnable(renderSeed=render_seed)
-        if sc.settings.get("sunTransform"):
-            pass
         mgr.RenderFrames(sc.frames)
         acc = tr.read_accumulated()
         c = tr.counters()
-        viol = tr.phase_profile()["filter_violations"][0] if lib is api else 0
+        viol = tr.phase_profile()["filter_violations"][0] if stats else 0
         out.append((acc, [c[k] for k in KEYS], viol))
         tr.close()
-    (a, ca, viol), (b, cb, _) = out
-    same = a.view(np.uint32) == b.view(np.uint32)
-    assert same.all(), f"seed {seed}: {int((~same.all(axis=-1)).sum())} pixels differ"
-    assert ca == cb, (seed, ca, cb)
+    _compare(out, f"seed {seed}")
+
+
+def _three(api, orc):
+    """(library, tracer, stats?) for the three renders every case gets: the SHIPPED kernel instantiation
+    (rt_trace_kernel<false, ...>: what bench.py times), the STATS instantiation (detailed counters + the filter
+    audits; a different binary) and the oracle."""
+    return ((api, api.create_tracer(0), False), (api, api.create_tracer(0), True), (orc, orc.create_tracer(8), False))
+
+
+def _compare(out, what=""):
+    (a0, c0, _), (a, ca, viol), (b, cb, _) = out
+    for name, img in (("shipped", a0), ("stats", a)):
+        same = img.view(np.uint32) == b.view(np.uint32)
+        assert same.all(), f"{what} ({name} instantiation): {int((~same.all(axis=-1)).sum())} pixels differ"
+    assert ca == cb, (what, ca, cb)
+    assert c0[KEYS.index("segments")] == cb[KEYS.index("segments")] and c0[-1] == cb[-1]
     assert viol == 0
+    return ca
 
 
 def crowded_scene(pkg, n_models, n_spheres, seed=7):
@@ -91,22 +103,20 @@ def crowded_scene(pkg, n_models, n_spheres, seed=7):
                                                         (200, 4, 1), (333, 0, 0)])
 def test_more_models_and_spheres_than_one_mask_word(pkg, api, orc, n_models, n_spheres, quality):
     out = []
-    for lib, tr in ((api, api.create_tracer(0)), (orc, orc.create_tracer(8))):
+    for lib, tr, stats in _three(api, orc):
         sc = crowded_scene(pkg, n_models, n_spheres)
         sc.settings["bvhQuality"] = quality   # 2 = no BVH: every root is a leaf (flat kernel variant)
-        if lib is api:
+        if stats:
             tr.enable_stats(True)
         mgr = sc.make_manager(tr, lib)
         mgr.OnEnable(renderSeed=11)
         mgr.RenderFrames(sc.frames)
         acc = tr.read_accumulated()
         c = tr.counters()
-        viol = tr.phase_profile()["filter_violations"][0] if lib is api else 0
+        viol = tr.phase_profile()["filter_violations"][0] if stats else 0
         out.append((acc, [c[k] for k in KEYS], viol))
         tr.close()
-    (a, ca, viol), (b, cb, _) = out
-    assert (a.view(np.uint32) == b.view(np.uint32)).all()
-    assert ca == cb and viol == 0
+    ca = _compare(out, f"{n_models} models, {n_spheres} spheres")
     assert ca[KEYS.index("modelVisits")] == ca[KEYS.index("segments")] * n_models
 
 
@@ -115,9 +125,9 @@ def test_two_level_model_hierarchy_follows_moving_models(pkg, api, orc):
     filter boxes, the chunk boxes and the spatial clustering are rebuilt and uploaded stream-ordered by
     rt_update_models; every frame must still equal the oracle (which simply walks all 200 models)."""
     out = []
-    for lib, tr in ((api, api.create_tracer(0)), (orc, orc.create_tracer(8))):
+    for lib, tr, stats in _three(api, orc):
         sc = crowded_scene(pkg, 200, 3, seed=21)
-        if lib is api:
+        if stats:
             tr.enable_stats(True)
         mgr = sc.make_manager(tr, lib)
         mgr.OnEnable(renderSeed=5)
@@ -128,12 +138,10 @@ def test_two_level_model_hierarchy_follows_moving_models(pkg, api, orc):
                     m.transform.position = (p[0] + 0.37 * ((i % 7) - 3), p[1], p[2] - 0.21 * ((i % 5) - 2))
             mgr.RenderFrame()
         c = tr.counters()
-        viol = tr.phase_profile()["filter_violations"][0] if lib is api else 0
+        viol = tr.phase_profile()["filter_violations"][0] if stats else 0
         out.append((tr.read_accumulated(), [c[k] for k in KEYS], viol))
         tr.close()
-    (a, ca, viol), (b, cb, _) = out
-    assert (a.view(np.uint32) == b.view(np.uint32)).all()
-    assert ca == cb and viol == 0
+    _compare(out, "200 moving models")
 
 
 @pytest.mark.parametrize("seed", range(6))

@@ -28,14 +28,24 @@ def rel_err(a, b):
 
 
 def pair(pkg, api, orc, cfg, w, h, frames, seed=1, scene_kw=None, tweak=None, stats=True):
+    """HIP image + counters, oracle image + counters.  The HIP image is the SHIPPED kernel instantiation's
+    (rt_trace_kernel<false, ...>, the one bench.py times); with stats=True the scene is rendered a second time by the
+    STATS instantiation (a different binary: detailed counters, audits, spills) — the two images must agree bit for
+    bit and in the one counter both keep (segments); the detailed counters returned are the stats run's."""
     g = api.create_tracer(0)
-    if stats:
-        g.enable_stats(True)
     c = orc.create_tracer(8)
     a, _ = render(pkg, api, g, cfg, w, h, frames, seed, scene_kw, tweak)
     b, _ = render(pkg, orc, c, cfg, w, h, frames, seed, scene_kw, tweak)
     ca, cb = g.counters(), c.counters()
     g.close(), c.close()
+    assert ca["segments"] == cb["segments"] and ca["pixelFrames"] == cb["pixelFrames"]
+    if stats:
+        g2 = api.create_tracer(0)
+        g2.enable_stats(True)
+        a2, _ = render(pkg, api, g2, cfg, w, h, frames, seed, scene_kw, tweak)
+        ca = g2.counters()
+        g2.close()
+        assert bits_equal(a, a2), "shipped and STATS instantiations disagree"
     return a, b, ca, cb
 
 

@@ -1,0 +1,92 @@
+"""The one-process-per-GPU path on the real library (sorts last on purpose: these tests spawn torch.distributed
+jobs, and a failure here must not hide the parity suites from a `pytest -x` run).
+
+A 1-GPU box stands in for N GPUs: every rank opens its own context on device 0 (RT_BENCH_ONE_DEVICE=1) and the
+collective runs over gloo (RCCL refuses two ranks on one device) — the partition, the bound render targets, the
+gather and bench.py's own N > 1 bookkeeping are the code the driver's SCALE run executes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _report(p):
+    """Head AND tail of both streams: the first failing rank's traceback is usually not in the last 4 KB."""
+    def cut(t):
+        return t if len(t) <= 12000 else t[:6000] + "\n...[cut]...\n" + t[-6000:]
+    tagged = "\n".join(l for l in p.stderr.splitlines() if l.startswith("[rank "))
+    return f"rc={p.returncode}\n--- rank-tagged failures\n{tagged}\n--- stdout\n{cut(p.stdout)}\n--- stderr\n{cut(p.stderr)}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,cfg", [(2, 3), (3, 2)])
+def test_partitioned_contexts_bound_targets_and_gather_on_the_gpu(world, cfg):
+    """rt_set_partition + rt_bind_render_targets + the gather, together, on the real library (one device,
+    `world` processes, gloo for the collective) == the oracle's single image."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "_dist_worker.py"), "gpu", str(cfg)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, _report(p)
+    assert "DIST_GPU_OK" in p.stdout
+
+
+def _bench(world, *extra):
+    env = dict(os.environ, RT_BENCH_ONE_DEVICE="1", RT_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--no-cpu-baseline", "--no-pmc", *extra],
+                       capture_output=True, text=True, timeout=1500, env=env)
+    assert p.returncode == 0, _report(p)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, _report(p)
+    return json.loads(lines[0])
+
+
+def _check_multi_rank_line(d, world, steps, resolution):
+    assert d["n_gpus"] == world and d["steps"] == steps and d["resolution"] == resolution
+    assert d["value"] > 0 and d["gather_ms"] is not None and d["gather_error"] is None
+    # every rank took part and said which device it ran on (one shared device here: the test hook)
+    assert d["ranks_seen"] == world
+    assert sorted(r["rank"] for r in d["devices_seen"]) == list(range(world))
+    assert len({r["pid"] for r in d["devices_seen"]}) == world
+    assert d["distinct_devices"] == 1
+    # the gathered image holds every frame of every rank's strips ...
+    assert d["gathered_image_complete"] is True, d["gathered_image"]
+    assert d["gathered_image"]["alpha_min"] == d["gathered_image"]["alpha_max"] == d["gathered_image"]["alpha_expected"]
+    # ... and equals the oracle's on strips owned by every rank
+    par = d["gathered_image"]["parity_vs_oracle"]
+    assert par["bit_identical"] is True and par["rel_l2_per_channel"] == [0.0, 0.0, 0.0], par
+    assert par["ranks_covered"] == list(range(world))
+    assert d["diagnostics"] == []
+
+
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts the two ranks itself (strong scaling on the
+    BASELINE image); the line it prints proves both ranks rendered and that the gathered image is the oracle's."""
+    d = _bench(2, "--steps", "3", "--warmup", "1")
+    assert d["scaling"] == "strong"
+    _check_multi_rank_line(d, 2, 3, [1920, 1080])
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_on_the_north_star_workload():
+    """BASELINE.json configs[4] as the driver's 8-GPU run executes it (3840x2160, 12 bounces, 983k triangles, image
+    row-tiled over 8 ranks), reduced to 2 steps, the 8 ranks sharing this box's GPU."""
+    d = _bench(8, "--config", "5", "--steps", "2", "--warmup", "1", "--no-batched")
+    _check_multi_rank_line(d, 8, 2, [3840, 2160])
