@@ -76,8 +76,10 @@ int main(int argc, char** argv)
             };
             ok(rt_create_multi(devices.data(), (int)devices.size(), &m), "rt_create_multi");
             ok(rt_multi_resize(m, width, height), "rt_multi_resize");
+            auto u0 = std::chrono::steady_clock::now();
             ok(rt_multi_upload_scene(m, mgr.meshInfo.data(), (int)mgr.meshInfo.size(), mgr.triangles.data(), (int)mgr.triangles.size(),
                                      mgr.nodes.data(), (int)mgr.nodes.size(), mgr.sphereBuffer.data(), (int)mgr.sphereBuffer.size()), "rt_multi_upload_scene");
+            double uploadMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - u0).count();
             RtParams p = mgr.ShaderParams();
             p.frame = 1;
             ok(rt_multi_set_params(m, &p), "rt_multi_set_params");
@@ -94,8 +96,9 @@ int main(int argc, char** argv)
             RtCounters c;
             ok(rt_multi_get_counters(m, &c), "rt_multi_get_counters");
             printf("{\"host\": \"c++\", \"config\": %d, \"width\": %d, \"height\": %d, \"frames\": %d, \"segments\": %llu, \"devices\": %d, "
-                   "\"wall_ms\": %.4f, \"Mrays_per_s\": %.1f}\n",
-                   config, width, height, frames, (unsigned long long)c.segments, rt_multi_count(m), ms, ms > 0 ? c.segments / ms / 1e3 : 0.0);
+                   "\"wall_ms\": %.4f, \"Mrays_per_s\": %.1f, \"upload_ms\": %.3f, \"gather_ms\": %.3f}\n",
+                   config, width, height, frames, (unsigned long long)c.segments, rt_multi_count(m), ms, ms > 0 ? c.segments / ms / 1e3 : 0.0,
+                   uploadMs, rt_multi_last_gather_ms(m));
             rt_destroy_multi(m);
         } else {
             mgr.OnEnable(seed);

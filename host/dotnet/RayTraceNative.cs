@@ -162,6 +162,7 @@ namespace RayTraceHost
         [DllImport(Lib)] public static extern int rt_multi_synchronize(IntPtr multi);
         [DllImport(Lib)] public static extern int rt_gather_accumulated(IntPtr multi, [Out] float[] rgba, UIntPtr bytes);
         [DllImport(Lib)] public static extern int rt_multi_get_counters(IntPtr multi, out RtCounters c);
+        [DllImport(Lib)] public static extern double rt_multi_last_gather_ms(IntPtr multi);
 
         public static void Check(IntPtr ctx, int status)
         {

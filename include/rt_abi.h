@@ -188,7 +188,9 @@ int rt_local_to_global_row(const RtContext* ctx, int local_row);
  * each local_rows*W*16 bytes, e.g. torch tensors to be gathered with RCCL.
  * Passing NULL for either returns to the library-owned buffer. */
 int rt_bind_render_targets(RtContext* ctx, void* d_frame_render, void* d_accumulated);
-/* Device pointers of the current targets (library-owned or bound). */
+/* Device pointers of the current targets (library-owned or bound).  Launches the frames rt_render_frame still holds
+ * back; a host that reads the targets directly (after its own stream/device synchronise) instead of through rt_read_*
+ * must call this or rt_flush/rt_synchronize first — frames are launched lazily (see rt_render_frame). */
 int rt_get_render_targets(RtContext* ctx, void** d_frame_render, void** d_accumulated);
 
 /* ---- scene: RCM:143-161 InitBVH (ComputeBuffer create + SetData) ----------- */
@@ -271,6 +273,8 @@ int rt_multi_count(const RtMulti* m);
 /* The i-th context, for per-context calls (counters, timers, display, rt_last_error ...). */
 RtContext* rt_multi_context(RtMulti* m, int i);
 int rt_multi_resize(RtMulti* m, int width, int height);
+/* Validated and re-laid out once on the host; context 0 is filled from the host, every other context copies context
+ * 0's device arrays on its own stream (device to device, xGMI between different GPUs), all destinations at once. */
 int rt_multi_upload_scene(RtMulti* m, const RtModel* models, int n_models, const RtTriangle* triangles, int n_triangles,
                           const RtBVHNode* nodes, int n_nodes, const RtSphere* spheres, int n_spheres);
 int rt_multi_update_models(RtMulti* m, const RtModel* models, int n_models);
@@ -279,10 +283,14 @@ int rt_multi_set_params(RtMulti* m, const RtParams* params);
 int rt_multi_reset_accumulation(RtMulti* m);
 int rt_multi_render_frame(RtMulti* m);
 int rt_multi_render_frames(RtMulti* m, int n);
+/* Frames held back by any context are launched on ALL devices before the host waits for the first one. */
 int rt_multi_synchronize(RtMulti* m);
-/* bytes must be H*W*16.  Synchronises every context. */
+/* bytes must be H*W*16.  Synchronises every context: held frames are launched everywhere, every device's tile is
+ * copied to pinned host memory on its own stream (all devices concurrently) and scattered to its global rows. */
 int rt_gather_accumulated(RtMulti* m, float* rgba, size_t bytes);
 int rt_gather_frame(RtMulti* m, float* rgba, size_t bytes);
+/* Wall time of the last gather (copies + scatter, after the flush), milliseconds. */
+double rt_multi_last_gather_ms(const RtMulti* m);
 /* Sum of the contexts' counters (gpuMs: the maximum). */
 int rt_multi_get_counters(RtMulti* m, RtCounters* out);
 

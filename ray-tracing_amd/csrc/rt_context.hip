@@ -18,6 +18,8 @@
 #include <string>
 #include <vector>
 
+#include <chrono>
+
 #include "rt_kernels.h"
 
 #ifndef RT_MAX_FUSED_FRAMES
@@ -108,7 +110,7 @@ struct RtContext {
     /* pinned staging ring of the per-frame update calls (rt_update_models / rt_update_spheres): the
      * uploads are enqueued on the render stream, no host synchronisation */
     struct Staging { void* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool inFlight = false; };
-    Staging staging[8];
+    Staging staging[24]; /* one animated frame uses up to 8 (rt_update_models 4 + rt_update_spheres 4): three frames in flight */
     int stagingNext = 0;
     uint64_t updateUploads = 0, updateSkips = 0; /* diagnostics: uploads enqueued / calls that changed nothing */
     /* Launch tuner (scheduling only, results do not depend on it): the suspension threshold of the traversal loop has two
@@ -189,13 +191,14 @@ static void flush_timer(RtContext* ctx)
 
 /* Stream-ordered host->device upload: the bytes are copied into a pinned staging slot now and the
  * transfer is enqueued on the (joined) render stream, i.e. after every frame already enqueued and
- * before the next one; the caller's memory is free on return and the host never waits for the GPU
- * (only when all 8 slots are still in flight, which a per-frame caller does not reach). */
+ * before the next one; the caller's memory is free on return and the host waits for the GPU only when the
+ * slot it is about to reuse is still in flight: a host that animates models AND spheres every frame uses 8 of the 24
+ * slots per frame, i.e. it blocks once it is three frames ahead of the GPU. */
 static int stage_upload(RtContext* ctx, void* dst, const void* src, size_t bytes)
 {
     if (!bytes) return RT_OK;
     RtContext::Staging& s = ctx->staging[ctx->stagingNext];
-    ctx->stagingNext = (ctx->stagingNext + 1) % 8;
+    ctx->stagingNext = (ctx->stagingNext + 1) % (int)(sizeof(ctx->staging) / sizeof(ctx->staging[0]));
     if (s.inFlight) {
         HIP_TRY(ctx, hipEventSynchronize(s.done));
         s.inFlight = false;
@@ -228,7 +231,9 @@ static int flush_pending(RtContext* ctx)
     const int n = ctx->pending;
     ctx->pending = 0;
     hipSetDevice(ctx->device);
-    return launch_frames(ctx, ctx->frame - n, n);
+    const int rc = launch_frames(ctx, ctx->frame - n, n);
+    if (rc != RT_OK) ctx->frame -= n; /* the held frames never ran: the frame counter says so (the caller may retry) */
+    return rc;
 }
 #define RT_FLUSH(ctx)                         \
     do {                                      \
@@ -418,6 +423,8 @@ int rt_bind_render_targets(RtContext* ctx, void* d_frame, void* d_accum)
 int rt_get_render_targets(RtContext* ctx, void** d_frame, void** d_accum)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    /* a host that reads the targets after its own device synchronise must find every requested frame at least launched */
+    RT_FLUSH(ctx);
     if (d_frame) *d_frame = ctx->boundFrame ? ctx->boundFrame : ctx->ownFrame;
     if (d_accum) *d_accum = ctx->boundAccum ? ctx->boundAccum : ctx->ownAccum;
     return RT_OK;
@@ -795,18 +802,36 @@ static int refresh_chunks(RtContext* ctx, const std::vector<DFilter>& filters)
     return stage_upload(ctx, ctx->dChunks, chunks.data(), sizeof(DChunk) * chunks.size());
 }
 
-extern "C" {
+/* The host side of rt_upload_scene: everything validated and re-laid out ONCE, ready to be uploaded to any number of
+ * contexts (rt_multi_upload_scene prepares once for all its devices). */
+struct PreparedScene {
+    std::vector<float> sph;
+    float sphereBound = 0;
+    std::vector<DMaterial> mats;
+    std::vector<DModel> dmodels;
+    std::vector<DPair> pairs;
+    std::vector<DTri> dtris;
+    std::vector<DTriN> dnorms;
+    std::vector<uint32_t> bigLeaves;
+    std::vector<DFilter> filters;
+    std::vector<DChunk> chunks;
+    int nFiltered = 0, extWords = 0;
+    float maxOrigin = 0;
+    std::vector<RtBVHNode> rootChildren;
+    std::vector<uint32_t> rootCodes;
+    std::vector<RtModel> hModels;
+    std::vector<RtSphere> hSpheres;
+    int nTris = 0, maxHeight = 1;
+    bool flat = true;
+};
 
-int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const RtTriangle* triangles, int n_triangles,
-                    const RtBVHNode* nodes, int n_nodes, const RtSphere* spheres, int n_spheres)
+/* errors are reported on `ctx` (may be any context of the caller) */
+static int prepare_scene(RtContext* ctx, const RtModel* models, int n_models, const RtTriangle* triangles, int n_triangles,
+                         const RtBVHNode* nodes, int n_nodes, const RtSphere* spheres, int n_spheres, PreparedScene& ps)
 {
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
-    RT_FLUSH(ctx);
     if (n_models < 0 || n_triangles < 0 || n_nodes < 0 || n_spheres < 0 || (n_models && !models) || (n_triangles && !triangles) ||
         (n_nodes && !nodes) || (n_spheres && !spheres))
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_scene: bad pointer/count");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
 
     /* ---- validate + re-lay out the BVHs reachable from the models */
     SceneBuilder sb;
@@ -814,8 +839,10 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
     sb.nNodes = n_nodes;
     sb.nTris = n_triangles;
     sb.pairOfFirstChild.assign((size_t)n_nodes + 1, -1);
-    std::vector<uint32_t> rootCodes(n_models);
-    std::vector<RtBVHNode> rootChildren((size_t)n_models * 2);
+    std::vector<uint32_t>& rootCodes = ps.rootCodes;
+    std::vector<RtBVHNode>& rootChildren = ps.rootChildren;
+    rootCodes.assign(n_models, 0u);
+    rootChildren.assign((size_t)n_models * 2, RtBVHNode());
     int maxHeight = 1;
     for (int i = 0; i < n_models; i++) {
         const RtModel& m = models[i];
@@ -854,8 +881,10 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
     }
 
     /* ---- triangles: RC:190-192 are ray independent, pre-difference them (same fp32 ops) */
-    std::vector<DTri> dtris((size_t)n_triangles);
-    std::vector<DTriN> dnorms((size_t)n_triangles);
+    std::vector<DTri>& dtris = ps.dtris;
+    std::vector<DTriN>& dnorms = ps.dnorms;
+    dtris.resize((size_t)n_triangles);
+    dnorms.resize((size_t)n_triangles);
     for (int i = 0; i < n_triangles; i++) {
         const RtTriangle& t = triangles[i];
         rt_f3 A = rt_v3(t.posA[0], t.posA[1], t.posA[2]);
@@ -873,51 +902,70 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
         memcpy(dnorms[i].n + 6, t.normC, 12);
     }
 
-    std::vector<float> sph;
-    float sphereBound = 0;
-    pack_spheres(spheres, n_spheres, sph, &sphereBound);
-    std::vector<DMaterial> mats((size_t)n_spheres + n_models);
-    for (int i = 0; i < n_spheres; i++) pack_material(spheres[i].material, mats[i]);
-    std::vector<DModel> dmodels(n_models);
+    pack_spheres(spheres, n_spheres, ps.sph, &ps.sphereBound);
+    ps.mats.resize((size_t)n_spheres + n_models);
+    for (int i = 0; i < n_spheres; i++) pack_material(spheres[i].material, ps.mats[i]);
+    ps.dmodels.resize(n_models);
     for (int i = 0; i < n_models; i++) {
-        pack_model(models[i], rootCodes[i], dmodels[i]);
-        pack_material(models[i].material, mats[n_spheres + i]);
+        pack_model(models[i], rootCodes[i], ps.dmodels[i]);
+        pack_material(models[i].material, ps.mats[n_spheres + i]);
     }
+    make_filters(models, n_models, rootCodes, rootChildren, spheres, n_spheres, ps.filters, &ps.maxOrigin);
+    make_chunks(ps.filters, ps.chunks, &ps.nFiltered, &ps.extWords);
+    ps.pairs.swap(sb.pairs);
+    ps.bigLeaves.swap(sb.bigLeaves);
+    ps.hModels.assign(models, models + n_models);
+    ps.hSpheres.assign(spheres, spheres + n_spheres);
+    ps.nTris = n_triangles;
+    ps.maxHeight = maxHeight;
+    ps.flat = true;
+    for (int i = 0; i < n_models; i++)
+        if (!(rootCodes[i] & RT_CODE_LEAF)) ps.flat = false;
+    return RT_OK;
+}
 
-    std::vector<DFilter> filters;
-    float maxOrigin = 0;
-    make_filters(models, n_models, rootCodes, rootChildren, spheres, n_spheres, filters, &maxOrigin);
+/* device copy of one scene array: from the host vector, or — `peer` — from the context that already holds it, device to
+ * device on this context's stream (xGMI when the devices differ; the caller synchronises the stream) */
+template <typename T>
+static int commit_vec(RtContext* ctx, T** dptr, const std::vector<T>& v, T* const* peerPtr, const RtContext* peer)
+{
+    if (!peer) return upload_vec(ctx, dptr, v.data(), v.size());
+    const size_t bytes = v.size() * sizeof(T);
+    HIP_TRY(ctx, hipMalloc(dptr, bytes ? bytes : sizeof(T)));
+    if (bytes) HIP_TRY(ctx, hipMemcpyPeerAsync(*dptr, ctx->device, *peerPtr, peer->device, bytes, ctx->stream));
+    return RT_OK;
+}
 
+static int commit_scene(RtContext* ctx, const PreparedScene& ps, const RtContext* peer)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
     free_scene(ctx);
     int rc;
-    if ((rc = upload_vec(ctx, &ctx->dSpheres, sph.data(), sph.size()))) return rc;
-    if ((rc = upload_vec(ctx, &ctx->dMaterials, mats.data(), mats.size()))) return rc;
-    if ((rc = upload_vec(ctx, &ctx->dModels, dmodels.data(), dmodels.size()))) return rc;
-    if ((rc = upload_vec(ctx, &ctx->dPairs, sb.pairs.data(), sb.pairs.size()))) return rc;
-    if ((rc = upload_vec(ctx, &ctx->dTris, dtris.data(), dtris.size()))) return rc;
-    if ((rc = upload_vec(ctx, &ctx->dNorms, dnorms.data(), dnorms.size()))) return rc;
-    if ((rc = upload_vec(ctx, &ctx->dBigLeaves, sb.bigLeaves.data(), sb.bigLeaves.size()))) return rc;
-    if ((rc = upload_vec(ctx, &ctx->dFilters, filters.data(), filters.size()))) return rc;
-    {
-        std::vector<DChunk> chunks;
-        make_chunks(filters, chunks, &ctx->nFiltered, &ctx->extWords);
-        if ((rc = upload_vec(ctx, &ctx->dChunks, chunks.data(), chunks.size()))) return rc;
-        ctx->nChunks = (int)chunks.size();
-    }
-    ctx->filterMaxOrigin = maxOrigin;
-    ctx->sphereBound = sphereBound;
-    ctx->hRootChildren = rootChildren;
-    ctx->hSpheres.assign(spheres, spheres + n_spheres);
-    ctx->nSpheres = n_spheres;
-    ctx->nModels = n_models;
-    ctx->nTris = n_triangles;
-    ctx->nPairs = (int)sb.pairs.size();
-    ctx->stackEntries = maxHeight;
-    ctx->flatScene = true;
-    for (int i = 0; i < n_models; i++)
-        if (!(rootCodes[i] & RT_CODE_LEAF)) ctx->flatScene = false;
-    ctx->hModels.assign(models, models + n_models);
-    ctx->hRootCodes = rootCodes;
+    if ((rc = commit_vec(ctx, &ctx->dSpheres, ps.sph, peer ? &peer->dSpheres : nullptr, peer))) return rc;
+    if ((rc = commit_vec(ctx, &ctx->dMaterials, ps.mats, peer ? &peer->dMaterials : nullptr, peer))) return rc;
+    if ((rc = commit_vec(ctx, &ctx->dModels, ps.dmodels, peer ? &peer->dModels : nullptr, peer))) return rc;
+    if ((rc = commit_vec(ctx, &ctx->dPairs, ps.pairs, peer ? &peer->dPairs : nullptr, peer))) return rc;
+    if ((rc = commit_vec(ctx, &ctx->dTris, ps.dtris, peer ? &peer->dTris : nullptr, peer))) return rc;
+    if ((rc = commit_vec(ctx, &ctx->dNorms, ps.dnorms, peer ? &peer->dNorms : nullptr, peer))) return rc;
+    if ((rc = commit_vec(ctx, &ctx->dBigLeaves, ps.bigLeaves, peer ? &peer->dBigLeaves : nullptr, peer))) return rc;
+    if ((rc = commit_vec(ctx, &ctx->dFilters, ps.filters, peer ? &peer->dFilters : nullptr, peer))) return rc;
+    if ((rc = commit_vec(ctx, &ctx->dChunks, ps.chunks, peer ? &peer->dChunks : nullptr, peer))) return rc;
+    ctx->nChunks = (int)ps.chunks.size();
+    ctx->nFiltered = ps.nFiltered;
+    ctx->extWords = ps.extWords;
+    ctx->filterMaxOrigin = ps.maxOrigin;
+    ctx->sphereBound = ps.sphereBound;
+    ctx->hRootChildren = ps.rootChildren;
+    ctx->hSpheres = ps.hSpheres;
+    ctx->nSpheres = (int)ps.hSpheres.size();
+    ctx->nModels = (int)ps.hModels.size();
+    ctx->nTris = ps.nTris;
+    ctx->nPairs = (int)ps.pairs.size();
+    ctx->stackEntries = ps.maxHeight;
+    ctx->flatScene = ps.flat;
+    ctx->hModels = ps.hModels;
+    ctx->hRootCodes = ps.rootCodes;
     ctx->haveScene = true;
     ctx->tuner.done = getenv("RT_SUSPEND") != nullptr; /* RT_SUSPEND=3|4 pins the threshold (tests, A/B runs) */
     ctx->tuner.decided = ctx->tuner.done ? atoi(getenv("RT_SUSPEND")) : 3;
@@ -927,6 +975,19 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
     ctx->tuner.next = 0;
     for (auto& pr : ctx->tuner.probe) pr.live = false;
     return RT_OK;
+}
+
+extern "C" {
+
+int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const RtTriangle* triangles, int n_triangles,
+                    const RtBVHNode* nodes, int n_nodes, const RtSphere* spheres, int n_spheres)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
+    PreparedScene ps;
+    int rc = prepare_scene(ctx, models, n_models, triangles, n_triangles, nodes, n_nodes, spheres, n_spheres, ps);
+    if (rc) return rc;
+    return commit_scene(ctx, ps, nullptr);
 }
 
 int rt_update_models(RtContext* ctx, const RtModel* models, int n_models)
@@ -1623,8 +1684,22 @@ int rt_debug_math_eval(RtContext* ctx, int op, const float* x, const float* y, f
  * ---------------------------------------------------------------------------------------- */
 struct RtMulti {
     std::vector<RtContext*> ctx;
-    std::vector<float> tile; /* staging of one context's packed rows */
+    /* pinned staging of the gather: every context's packed rows, copied device -> host concurrently */
+    void* pinned = nullptr;
+    size_t pinnedBytes = 0;
+    double lastGatherMs = 0;
 };
+
+/* launch what every context holds back BEFORE waiting for any of them: a per-context synchronise in a loop would start
+ * device i+1's held frames only after device i has finished */
+static int multi_flush_all(RtMulti* m)
+{
+    for (RtContext* c : m->ctx) {
+        int rc = rt_flush(c);
+        if (rc != RT_OK) return rc;
+    }
+    return RT_OK;
+}
 
 int rt_create_multi(const int* device_ids, int n_devices, RtMulti** out)
 {
@@ -1651,6 +1726,7 @@ void rt_destroy_multi(RtMulti* m)
 {
     if (!m) return;
     for (RtContext* c : m->ctx) rt_destroy(c);
+    if (m->pinned) hipHostFree(m->pinned);
     delete m;
 }
 
@@ -1671,7 +1747,27 @@ int rt_multi_resize(RtMulti* m, int width, int height) { RT_MULTI_FORWARD(rt_res
 int rt_multi_upload_scene(RtMulti* m, const RtModel* models, int n_models, const RtTriangle* triangles, int n_triangles,
                           const RtBVHNode* nodes, int n_nodes, const RtSphere* spheres, int n_spheres)
 {
-    RT_MULTI_FORWARD(rt_upload_scene(c, models, n_models, triangles, n_triangles, nodes, n_nodes, spheres, n_spheres));
+    /* validated and re-laid out once; context 0 gets it from the host, the others copy context 0's device arrays
+     * (hipMemcpyPeerAsync on their own streams: all destinations at once, over xGMI between different devices) */
+    if (!m || m->ctx.empty()) return fail(nullptr, RT_ERR_INVALID_ARG, "null multi context");
+    int rc = multi_flush_all(m);
+    if (rc) return rc;
+    PreparedScene ps;
+    RtContext* c0 = m->ctx[0];
+    if ((rc = prepare_scene(c0, models, n_models, triangles, n_triangles, nodes, n_nodes, spheres, n_spheres, ps))) return rc;
+    if ((rc = commit_scene(c0, ps, nullptr))) return rc;
+    const bool peerCopies = getenv("RT_MULTI_PEER_UPLOAD") == nullptr || atoi(getenv("RT_MULTI_PEER_UPLOAD")) != 0;
+    for (size_t i = 1; i < m->ctx.size(); i++) {
+        rc = commit_scene(m->ctx[i], ps, peerCopies ? c0 : nullptr);
+        if (rc != RT_OK && peerCopies) rc = commit_scene(m->ctx[i], ps, nullptr); /* no peer path between the two: from the host */
+        if (rc != RT_OK) return rc;
+    }
+    for (size_t i = 1; i < m->ctx.size(); i++) { /* the copies read context 0's arrays: done before anyone may replace them */
+        RtContext* c = m->ctx[i];
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return RT_OK;
 }
 int rt_multi_update_models(RtMulti* m, const RtModel* models, int n_models) { RT_MULTI_FORWARD(rt_update_models(c, models, n_models)); }
 int rt_multi_update_spheres(RtMulti* m, const RtSphere* spheres, int n_spheres) { RT_MULTI_FORWARD(rt_update_spheres(c, spheres, n_spheres)); }
@@ -1679,7 +1775,14 @@ int rt_multi_set_params(RtMulti* m, const RtParams* params) { RT_MULTI_FORWARD(r
 int rt_multi_reset_accumulation(RtMulti* m) { RT_MULTI_FORWARD(rt_reset_accumulation(c)); }
 int rt_multi_render_frame(RtMulti* m) { RT_MULTI_FORWARD(rt_render_frame(c)); }
 int rt_multi_render_frames(RtMulti* m, int n) { RT_MULTI_FORWARD(rt_render_frames(c, n)); }
-int rt_multi_synchronize(RtMulti* m) { RT_MULTI_FORWARD(rt_synchronize(c)); }
+int rt_multi_synchronize(RtMulti* m)
+{
+    if (!m) return fail(nullptr, RT_ERR_INVALID_ARG, "null multi context");
+    int rc = multi_flush_all(m);
+    if (rc) return rc;
+    RT_MULTI_FORWARD(rt_synchronize(c));
+}
+double rt_multi_last_gather_ms(const RtMulti* m) { return m ? m->lastGatherMs : 0.0; }
 
 static int multi_gather(RtMulti* m, float* rgba, size_t bytes, bool accumulated)
 {
@@ -1687,23 +1790,54 @@ static int multi_gather(RtMulti* m, float* rgba, size_t bytes, bool accumulated)
     RtContext* c0 = m->ctx[0];
     const int W = c0->W, H = c0->H;
     if (!rgba || bytes != (size_t)W * H * 16) return fail(c0, RT_ERR_INVALID_ARG, "rt_gather: bytes %zu != H*W*16 = %zu", bytes, (size_t)W * H * 16);
+    const size_t rowBytes = (size_t)W * 16;
+    size_t total = 0;
     for (RtContext* c : m->ctx) {
         if (c->W != W || c->H != H) return fail(c0, RT_ERR_STATE, "rt_gather: contexts disagree on the resolution");
+        total += (size_t)c->localRows * rowBytes;
+    }
+    if (m->pinnedBytes < total) {
+        if (m->pinned) hipHostFree(m->pinned);
+        m->pinned = nullptr;
+        m->pinnedBytes = 0;
+        HIP_TRY(c0, hipHostMalloc(&m->pinned, total ? total : 16, hipHostMallocDefault));
+        m->pinnedBytes = total;
+    }
+    /* every device's held frames are launched, then every device's tile is on its way to pinned host memory (each on
+     * its own stream and its own link), and only then does the host wait — device by device, scattering the tile that
+     * has arrived while the others are still in flight */
+    int rc = multi_flush_all(m);
+    if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t off = 0;
+    for (RtContext* c : m->ctx) {
+        const size_t n = (size_t)c->localRows * rowBytes;
+        if (n) {
+            const float* src = accumulated ? (c->boundAccum ? c->boundAccum : c->ownAccum) : (c->boundFrame ? c->boundFrame : c->ownFrame);
+            HIP_TRY(c, hipSetDevice(c->device));
+            HIP_TRY(c, hipMemcpyAsync((char*)m->pinned + off, src, n, hipMemcpyDeviceToHost, joined(c)));
+        }
+        off += n;
+    }
+    off = 0;
+    for (RtContext* c : m->ctx) {
         const int rows = c->localRows;
-        if (!rows) continue;
-        const size_t rowBytes = (size_t)W * 16;
-        m->tile.resize((size_t)rows * W * 4);
-        int rc = accumulated ? rt_read_accumulated(c, m->tile.data(), (size_t)rows * rowBytes) : rt_read_frame(c, m->tile.data(), (size_t)rows * rowBytes);
-        if (rc != RT_OK) return rc;
+        const size_t n = (size_t)rows * rowBytes;
+        if (!n) continue;
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        flush_timer(c);
         /* packed local rows -> their global rows; a strip's rows are contiguous in both */
         for (int l = 0; l < rows;) {
             const int g = rt_local_to_global_row(c, l);
             int run = c->stripRows - (g % c->stripRows);
             if (run > rows - l) run = rows - l;
-            memcpy((char*)rgba + (size_t)g * rowBytes, (const char*)m->tile.data() + (size_t)l * rowBytes, (size_t)run * rowBytes);
+            memcpy((char*)rgba + (size_t)g * rowBytes, (const char*)m->pinned + off + (size_t)l * rowBytes, (size_t)run * rowBytes);
             l += run;
         }
+        off += n;
     }
+    m->lastGatherMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;
 }
 int rt_gather_accumulated(RtMulti* m, float* rgba, size_t bytes) { return multi_gather(m, rgba, bytes, true); }
@@ -1713,6 +1847,10 @@ int rt_multi_get_counters(RtMulti* m, RtCounters* out)
 {
     if (!m || !out) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_multi_get_counters: null argument");
     memset(out, 0, sizeof(*out));
+    {
+        int rc = multi_flush_all(m);
+        if (rc) return rc;
+    }
     for (RtContext* c : m->ctx) {
         RtCounters k;
         int rc = rt_get_counters(c, &k);
