@@ -1169,7 +1169,8 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
 #else
     const size_t slabBytes = 0;
 #endif
-    const size_t stackBytes = (size_t)(ctx->stackEntries + RT_PIXEL_FIELDS + (ctx->extWords ? 1 + ctx->extWords : 0)) * RT_WAVE * sizeof(uint32_t) + slabBytes;
+    const size_t coldBytes = ctx->flatScene ? (size_t)2 * RT_WAVE * 16 : 0; /* the FLAT variant keeps its pixel records in LDS (rt_kernels.h, PX_COLD) */
+    const size_t stackBytes = (size_t)(ctx->stackEntries + RT_PIXEL_FIELDS + (ctx->extWords ? 1 + ctx->extWords : 0)) * RT_WAVE * sizeof(uint32_t) + slabBytes + coldBytes;
     a.stackEntries = ctx->stackEntries;
     const bool many = ctx->nChunks > 0 && !ctx->flatScene;
     void (*kern)(const KArgs) = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_kernel<true, true> : rtk::rt_trace_kernel<false, true>)

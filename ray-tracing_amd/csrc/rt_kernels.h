@@ -237,7 +237,7 @@ struct Trav {
     unsigned long long cand; /* models [0,64) still to visit (bit m), from the lockstep root filter */
     int m;          /* current model index */
     uint32_t cur;   /* current node code, or RT_CODE_NEXT_MODEL */
-    int sp;         /* entries on this lane's LDS stack */
+    int sp;         /* entries on this lane's stack */
     bool rootStep;  /* the next inner step is the model's root (already counted by the filter) */
     rt_f3 lpos, ldir, linv; /* ray in the model's local space (RC:351-353) */
     int triBase;
@@ -789,7 +789,11 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
      * (two float4 per lane, [2][64] per wave, private to the lane that wrote them): LDS decides how many waves a CU holds
      * (stack + pixel fields: 160 KB / 6 waves per SIMD = 26 rows of 256 B), and every wave counts (§4.14).
      *   q[0] = (focus point xyz, pixelIndex)   q[1] = (linear pixel index, segment count at set-up, frame, -) */
-#define PX_COLD(c) ((c).pxCold + (size_t)blockIdx.x * (2 * RT_WAVE) + (size_t)lane) /* [wave][2][lane]: a wave's store covers 1 KB without gaps */
+    /* The FLAT variant has no traversal stack: its LDS is nearly empty (5 rows of 256 B per wave at 8 waves per SIMD), so
+     * its records live in LDS too ([2][64] float4 after the pixel fields) — no record traffic to memory at all, and the
+     * camera-ray phase reads its focus point back at LDS latency. */
+#define PX_COLD(c) (FLAT ? reinterpret_cast<float4*>(__builtin_assume_aligned(pxu - lane + RT_PIXEL_FIELDS * RT_WAVE, 16)) + lane \
+                         : ((c).pxCold + (size_t)blockIdx.x * (2 * RT_WAVE) + (size_t)lane)) /* [wave][2][lane]: a wave's store covers 1 KB without gaps */
 #define PXU(k) pxu[(k) * RT_WAVE]
 #define PXF(k) pxf[(k) * RT_WAVE]
     uint32_t rng = 0;
