@@ -106,9 +106,10 @@ __global__ void k_prepare(const float* verts, const int* indices, int ntri, GTri
 }
 
 /* ChooseSplit's candidate planes (BVH:183-250), in evaluation order; slot 15 = the (0, 0) fallback */
-__global__ void k_candidates(GNode* nodes, int first, int nActive, int quality, GCand* cands)
+__global__ void k_candidates(GNode* nodes, int first, int nActive, int quality, GCand* cands, int* counts)
 {
     int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a == nActive) counts[nActive] = 0; /* the scan's total lands here (the grid covers nActive + 1 threads) */
     if (a >= nActive) return;
     GNode& n = nodes[first + a];
     GCand* cd = cands + (size_t)a * GB_NCAND;
@@ -138,15 +139,9 @@ __global__ void k_candidates(GNode* nodes, int first, int nActive, int quality, 
         }
     }
     n.nCand = nc;
+    counts[a] = nc > 0 ? (n.count + GB_CHUNK - 1) / GB_CHUNK : 0; /* sweep chunks of this node */
 }
 
-__global__ void k_chunk_counts(const GNode* nodes, int first, int nActive, int* counts)
-{
-    int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= nActive) return;
-    const GNode& n = nodes[first + a];
-    counts[a] = n.nCand > 0 ? (n.count + GB_CHUNK - 1) / GB_CHUNK : 0;
-}
 __global__ void k_chunk_map(GNode* nodes, int first, int nActive, const int* chunkBase, const int* counts, int* chunkNode)
 {
     int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -221,6 +216,7 @@ __global__ void k_choose(GNode* nodes, int first, int nActive, int quality, cons
                          GBox* chosen, int* splitFlag)
 {
     int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a == nActive) splitFlag[nActive] = 0;
     if (a >= nActive) return;
     GNode& n = nodes[first + a];
     const int nc = n.nCand;
@@ -257,14 +253,10 @@ __global__ void k_choose(GNode* nodes, int first, int nActive, int quality, cons
 }
 
 /* children of the splitting nodes: breadth-first slots firstChild + 2 * rank */
-__global__ void k_children(GNode* nodes, int first, int nActive, const int* splitFlag, const int* splitRank, const GBox* chosen, int firstChild, int* maxChildCount)
+__global__ void k_children(GNode* nodes, int first, int nActive, const int* splitFlag, const int* splitRank, const GBox* chosen, int firstChild)
 {
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= nActive || !splitFlag[a]) return;
-    {
-        const int nl = chosen[a].nLeft, nr = nodes[first + a].count - nl;
-        atomicMax(maxChildCount, nl > nr ? nl : nr); /* bounds the next level's partition chains */
-    }
     GNode& n = nodes[first + a];
     const int li = firstChild + 2 * splitRank[a];
     n.left = li;
@@ -283,13 +275,14 @@ __global__ void k_children(GNode* nodes, int first, int nActive, const int* spli
 __global__ void k_flags(const GNode* nodes, const int* triNode, const GTri* tris, int ntri, int* flag)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == ntri) flag[ntri] = 0;
     if (g >= ntri) return;
     const int nd = triNode[g];
     int f = 0;
     if (nd >= 0 && nodes[nd].left >= 0) f = tris[g].c[nodes[nd].splitAxis] < nodes[nd].splitPos ? 1 : 0;
     flag[g] = f;
 }
-__global__ void k_tape(const GNode* nodes, const int* triNode, const int* flag, const int* S, int ntri, int* src)
+__global__ void k_tape(const GNode* nodes, const int* triNode, const int* flag, const int* S, int ntri, int* src, int* firstR)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= ntri) return;
@@ -297,6 +290,7 @@ __global__ void k_tape(const GNode* nodes, const int* triNode, const int* flag, 
     const int nd = triNode[g];
     if (nd < 0 || nodes[nd].left < 0) return;
     const GNode& n = nodes[nd];
+    if (!flag[g] && S[g] - S[n.start] == g - n.start) firstR[nd] = g; /* exactly one right-hand triangle has only lefts before it */
     /* every triangle before the first right-hand one goes left: firstR = start + (length of the leading run of lefts).
      * nLeft lefts in all; the leading run is found from the prefix sums: position p is in it iff S[p] - S[start] == p - start
      * and flag[p] == 1.  The first right-hand triangle is the first position where that fails. */
@@ -312,15 +306,6 @@ __global__ void k_tape(const GNode* nodes, const int* triNode, const int* flag, 
             src[g] = -1 - cl; /* provisional: resolved in k_tape2 once firstR of the node is known */
         }
     }
-}
-__global__ void k_first_right(GNode* nodes, const int* triNode, const int* flag, const int* S, int ntri, int* firstR)
-{
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ntri) return;
-    const int nd = triNode[g];
-    if (nd < 0 || nodes[nd].left < 0) return;
-    const int start = nodes[nd].start;
-    if (!flag[g] && S[g] - S[start] == g - start) firstR[nd] = g; /* exactly one right-hand triangle has only lefts before it */
 }
 __global__ void k_tape2(const GNode* nodes, const int* triNode, const int* firstR, int ntri, int* src)
 {
@@ -343,6 +328,23 @@ __global__ void k_jump(int ntri, int* src, int* changed)
         src[g] = t;
         if (changed) *changed = 1;
     }
+}
+/* after a few synchronous jumps: every thread follows what is left of its chain to the root (a position that copies
+ * itself).  Read-only walk over pointers that other threads only ever move FURTHER along the same chain, so a stale
+ * read is still on the chain; the walk ends at the same root whatever the interleaving.  Replaces a host loop of
+ * "three passes, read a flag back" rounds — two host synchronisations per level less. */
+__global__ void k_follow(int ntri, int* src)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ntri) return;
+    const volatile int* vs = src;
+    int s = vs[g];
+    for (;;) {
+        const int t = vs[s];
+        if (t == s) break;
+        s = t;
+    }
+    src[g] = s;
 }
 __global__ void k_scatter(const GNode* nodes, const int* triNode, const int* flag, const int* S, const int* firstR, const int* src, const GTri* tris, int ntri,
                           GTri* outTris, int* outTriNode)
@@ -428,7 +430,9 @@ __global__ void k_tri_index(const GTri* tris, int ntri, int* out)
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    ~DevBuf() { if (p) hipFree(p); }
+    /* no destructor: the pool below is thread-local, and a hipFree at thread or process exit may run after the HIP
+     * runtime is gone; rt_build_bvh_gpu_release() frees it explicitly, the process's teardown frees the rest */
+    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
     template <typename T>
     T* get(size_t n)
     {
@@ -453,7 +457,23 @@ struct DevBuf {
 
 static inline int blocks(size_t n, int t = 256) { return (int)((n + t - 1) / t); }
 
-int build(int device, const float* verts, const float* normals, int n_verts, const int32_t* indices, int n_indices, int quality,
+struct Pool { int device = -1; DevBuf b[22]; };
+static thread_local Pool g_pool;
+static const size_t GB_POOL_KEEP = (size_t)1 << 30; /* scratch kept between calls: at most 1 GiB (a 1M-triangle mesh needs ~0.6 GiB) */
+
+static void pool_release()
+{
+    if (g_pool.device >= 0) {
+        int prev = -1;
+        const bool have = hipGetDevice(&prev) == hipSuccess;
+        if (hipSetDevice(g_pool.device) == hipSuccess)
+            for (DevBuf& d : g_pool.b) d.release();
+        if (have) hipSetDevice(prev);
+    }
+    g_pool.device = -1;
+}
+
+static int build_impl(int device, const float* verts, const float* normals, int n_verts, const int32_t* indices, int n_indices, int quality,
           RtBVHNode* out_nodes, int* out_n_nodes, RtTriangle* out_tris, RtBvhStats* out_stats)
 {
     if (!verts || !normals || !indices || !out_nodes || !out_n_nodes || !out_tris || n_verts < 0 || n_indices < 0 || n_indices % 3)
@@ -501,9 +521,8 @@ int build(int device, const float* verts, const float* normals, int n_verts, con
     } else {
         /* device scratch is kept between calls (a scene build calls this once per mesh): hipMalloc/hipFree of twenty
          * buffers would otherwise cost more than the build of a small mesh */
-        struct Pool { int device = -1; DevBuf b[22]; };
-        static thread_local Pool pool;
-        if (pool.device != device) { for (DevBuf& d : pool.b) { if (d.p) hipFree(d.p); d.p = nullptr; d.cap = 0; } pool.device = device; }
+        Pool& pool = g_pool;
+        if (pool.device != device) { pool_release(); pool.device = device; }
         DevBuf &bVerts = pool.b[0], &bIdx = pool.b[1], &bTrisA = pool.b[2], &bTrisB = pool.b[3], &bNodeA = pool.b[4], &bNodeB = pool.b[5], &bFlag = pool.b[6],
                &bScan = pool.b[7], &bSrc = pool.b[8], &bNodes = pool.b[9], &bCands = pool.b[10], &bPartial = pool.b[11], &bChosen = pool.b[12], &bCounts = pool.b[13],
                &bBase = pool.b[14], &bChunkNode = pool.b[15], &bSplit = pool.b[16], &bRank = pool.b[17], &bFirstR = pool.b[18], &bTemp = pool.b[19], &bMisc = pool.b[20],
@@ -534,7 +553,6 @@ int build(int device, const float* verts, const float* normals, int n_verts, con
         lap("alloc + upload");
         std::vector<int> levelFirst;
         int first = 0, nActive = 1, total = 1;
-        int levelMaxCount = ntri; /* largest active node of the current level */
         GB_TRY(hipMemsetAsync(misc, 0, 16 * sizeof(int), 0));
         size_t tempBytes = 0;
         hipcub::DeviceScan::ExclusiveSum(nullptr, tempBytes, flag, S, ntri + 1);
@@ -549,9 +567,7 @@ int build(int device, const float* verts, const float* normals, int n_verts, con
             int* splitRank = bRank.get<int>((size_t)nActive + 1);
             GBox* chosen = bChosen.get<GBox>(nActive);
             if (!cands || !counts || !base || !splitFlag || !splitRank || !chosen) return RT_ERR_OOM;
-            hipLaunchKernelGGL(k_candidates, dim3(blocks(nActive)), dim3(256), 0, 0, nodes, first, nActive, quality, cands);
-            hipLaunchKernelGGL(k_chunk_counts, dim3(blocks(nActive)), dim3(256), 0, 0, nodes, first, nActive, counts);
-            GB_TRY(hipMemsetAsync(counts + nActive, 0, sizeof(int), 0));
+            hipLaunchKernelGGL(k_candidates, dim3(blocks(nActive + 1)), dim3(256), 0, 0, nodes, first, nActive, quality, cands, counts);
             size_t tb = 0;
             hipcub::DeviceScan::ExclusiveSum(nullptr, tb, counts, base, nActive + 1);
             if (tb > tempBytes) { tempBytes = tb; temp = bTemp.get<char>(tempBytes + 256); if (!temp) return RT_ERR_OOM; }
@@ -563,9 +579,8 @@ int build(int device, const float* verts, const float* normals, int n_verts, con
                 if (!chunkNode || !partial) return RT_ERR_OOM;
                 hipLaunchKernelGGL(k_chunk_map, dim3(blocks(nActive)), dim3(256), 0, 0, nodes, first, nActive, base, counts, chunkNode);
                 hipLaunchKernelGGL(k_sweep, dim3(maxChunks), dim3(64), 0, 0, nodes, first, chunkNode, base + nActive, cands, trisA, partial);
-                hipLaunchKernelGGL(k_choose, dim3(blocks(nActive)), dim3(256), 0, 0, nodes, first, nActive, quality, cands, partial, counts, chosen, splitFlag);
+                hipLaunchKernelGGL(k_choose, dim3(blocks(nActive + 1)), dim3(256), 0, 0, nodes, first, nActive, quality, cands, partial, counts, chosen, splitFlag);
             }
-            GB_TRY(hipMemsetAsync(splitFlag + nActive, 0, sizeof(int), 0));
             tb = 0;
             hipcub::DeviceScan::ExclusiveSum(nullptr, tb, splitFlag, splitRank, nActive + 1);
             if (tb > tempBytes) { tempBytes = tb; temp = bTemp.get<char>(tempBytes + 256); if (!temp) return RT_ERR_OOM; }
@@ -573,39 +588,22 @@ int build(int device, const float* verts, const float* normals, int n_verts, con
             int nSplit = 0;
             GB_TRY(hipMemcpy(&nSplit, splitRank + nActive, sizeof(int), hipMemcpyDeviceToHost));
             if ((size_t)total + 2 * (size_t)nSplit > maxNodes) return RT_ERR_SCENE; /* degenerate input: see rt_build_bvh */
-            int jumpPasses = 1; /* a tape chain is shorter than its node and halves every pass */
-            while ((1 << jumpPasses) < levelMaxCount) jumpPasses++;
             if (nSplit > 0) {
                 int* firstR = bFirstR.get<int>(total);
                 if (!firstR) return RT_ERR_OOM;
-                hipLaunchKernelGGL(k_children, dim3(blocks(nActive)), dim3(256), 0, 0, nodes, first, nActive, splitFlag, splitRank, chosen, total, misc + 1);
+                hipLaunchKernelGGL(k_children, dim3(blocks(nActive)), dim3(256), 0, 0, nodes, first, nActive, splitFlag, splitRank, chosen, total);
                 GB_TRY(hipMemsetAsync(firstR, 0xff, sizeof(int) * (size_t)total, 0));
-                hipLaunchKernelGGL(k_flags, dim3(blocks(ntri)), dim3(256), 0, 0, nodes, nodeOfA, trisA, ntri, flag);
-                GB_TRY(hipMemsetAsync(flag + ntri, 0, sizeof(int), 0));
+                hipLaunchKernelGGL(k_flags, dim3(blocks(ntri + 1)), dim3(256), 0, 0, nodes, nodeOfA, trisA, ntri, flag);
                 tb = tempBytes;
                 hipcub::DeviceScan::ExclusiveSum(temp, tb, flag, S, ntri + 1);
-                hipLaunchKernelGGL(k_first_right, dim3(blocks(ntri)), dim3(256), 0, 0, nodes, nodeOfA, flag, S, ntri, firstR);
-                hipLaunchKernelGGL(k_tape, dim3(blocks(ntri)), dim3(256), 0, 0, nodes, nodeOfA, flag, S, ntri, src);
+                hipLaunchKernelGGL(k_tape, dim3(blocks(ntri)), dim3(256), 0, 0, nodes, nodeOfA, flag, S, ntri, src, firstR);
                 hipLaunchKernelGGL(k_tape2, dim3(blocks(ntri)), dim3(256), 0, 0, nodes, nodeOfA, firstR, ntri, src);
-                /* pointer jumping: a chain is at most as long as its node has triangles and halves every pass */
-                /* (the bound is rarely reached: after every third pass a flag says whether any pointer still moved) */
-                for (int it = 0; it < jumpPasses;) {
-                    GB_TRY(hipMemsetAsync(misc + 2, 0, sizeof(int), 0));
-                    int k = 0;
-                    for (; k < 3 && it < jumpPasses; k++, it++)
-                        hipLaunchKernelGGL(k_jump, dim3(blocks(ntri)), dim3(256), 0, 0, ntri, src, k == 2 || it + 1 == jumpPasses ? misc + 2 : (int*)nullptr);
-                    if (it >= jumpPasses) break;
-                    int moved = 0;
-                    GB_TRY(hipMemcpy(&moved, misc + 2, sizeof(int), hipMemcpyDeviceToHost));
-                    if (!moved) break;
-                }
+                /* pointer jumping: three synchronous passes shorten every chain eightfold, then each position follows the rest */
+                for (int it = 0; it < 3; it++) hipLaunchKernelGGL(k_jump, dim3(blocks(ntri)), dim3(256), 0, 0, ntri, src, (int*)nullptr);
+                hipLaunchKernelGGL(k_follow, dim3(blocks(ntri)), dim3(256), 0, 0, ntri, src);
                 hipLaunchKernelGGL(k_scatter, dim3(blocks(ntri)), dim3(256), 0, 0, nodes, nodeOfA, flag, S, firstR, src, trisA, ntri, trisB, nodeOfB);
                 std::swap(trisA, trisB);
                 std::swap(nodeOfA, nodeOfB);
-            }
-            if (nSplit > 0) { /* children sizes of this level = the next level's node sizes */
-                GB_TRY(hipMemcpy(&levelMaxCount, misc + 1, sizeof(int), hipMemcpyDeviceToHost));
-                GB_TRY(hipMemsetAsync(misc + 1, 0, sizeof(int), 0));
             }
             first = total;
             nActive = 2 * nSplit;
@@ -684,7 +682,24 @@ int build(int device, const float* verts, const float* normals, int n_verts, con
     return RT_OK;
 }
 
+int build(int device, const float* verts, const float* normals, int n_verts, const int32_t* indices, int n_indices, int quality,
+          RtBVHNode* out_nodes, int* out_n_nodes, RtTriangle* out_tris, RtBvhStats* out_stats)
+{
+    int prev = -1;
+    const bool havePrev = hipGetDevice(&prev) == hipSuccess; /* the caller's current device is the caller's business: put it back */
+    if (out_n_nodes) *out_n_nodes = 0;                       /* every error path leaves 0 nodes */
+    const int rc = build_impl(device, verts, normals, n_verts, indices, n_indices, quality, out_nodes, out_n_nodes, out_tris, out_stats);
+    if (rc != RT_OK && out_n_nodes) *out_n_nodes = 0;
+    size_t held = 0;
+    for (const DevBuf& d : g_pool.b) held += d.cap;
+    if (held > GB_POOL_KEEP) pool_release(); /* a huge mesh does not pin its scratch for the life of the thread */
+    if (havePrev) hipSetDevice(prev);
+    return rc;
+}
+
 } // namespace gbvh
+
+extern "C" void rt_build_bvh_gpu_release(void) { gbvh::pool_release(); }
 
 extern "C" int rt_build_bvh_gpu(int device_id, const float* verts, const float* normals, int n_verts, const int32_t* indices, int n_indices,
                                 int quality, RtBVHNode* out_nodes, int* out_n_nodes, RtTriangle* out_tris, RtBvhStats* out_stats)

@@ -397,6 +397,11 @@ int rt_resize(RtContext* ctx, int width, int height)
     }
     ctx->boundFrame = ctx->boundAccum = nullptr;
     ctx->orderTiles = 0; /* tile costs belong to the old geometry */
+    if (ctx->dStaging && ctx->stagingBytes != (size_t)RT_MAX_FUSED_FRAMES * ctx->localRows * width * 16) {
+        hipFree(ctx->dStaging); /* sized for the old image (16 frames of it): re-made by the next fused launch */
+        ctx->dStaging = nullptr;
+        ctx->stagingBytes = 0;
+    }
     return RT_OK;
 }
 
@@ -1244,9 +1249,26 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
             hipFree(ctx->dStaging);
             ctx->dStaging = nullptr;
             ctx->stagingBytes = 0;
-            const size_t cap = (size_t)RT_MAX_FUSED_FRAMES * nPix * 16; /* grow once to the largest batch */
-            HIP_TRY(ctx, hipMalloc(&ctx->dStaging, cap));
-            ctx->stagingBytes = cap;
+            /* grow once to the largest batch; if memory is short, to this batch; if even that fails the frames go out
+             * one launch each (a single-frame launch needs no staging) — a render call never fails for want of scratch */
+            const size_t cap = (size_t)RT_MAX_FUSED_FRAMES * nPix * 16;
+            size_t got = cap;
+            if (hipMalloc(&ctx->dStaging, cap) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->dStaging = nullptr;
+                got = need;
+                if (hipMalloc(&ctx->dStaging, need) != hipSuccess) {
+                    (void)hipGetLastError();
+                    ctx->dStaging = nullptr;
+                    if (ctx->lptEnabled) ctx->framesSinceResize -= nFrames; /* counted again by the single launches */
+                    for (int f = 0; f < nFrames; f++) {
+                        const int rc1 = launch_frames(ctx, frame0 + f, 1);
+                        if (rc1 != RT_OK) return rc1;
+                    }
+                    return RT_OK;
+                }
+            }
+            ctx->stagingBytes = got;
         }
         a.staging = ctx->dStaging;
         a.stagingStride = (uint32_t)nPix;

@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "rt_update_spheres", "rt_set_params", "rt_reset_accumulation", "rt_render_frame", "rt_render_frames",
     "rt_synchronize", "rt_get_frame", "rt_read_frame", "rt_read_accumulated", "rt_display", "rt_display_srgb8",
     "rt_write_accumulated", "rt_timer_begin", "rt_timer_end",
-    "rt_enable_stats", "rt_reset_counters", "rt_get_counters", "rt_build_bvh", "rt_build_bvh_mt", "rt_build_bvh_gpu", "rt_camera_view_params", "rt_version",
+    "rt_enable_stats", "rt_reset_counters", "rt_get_counters", "rt_build_bvh", "rt_build_bvh_mt", "rt_build_bvh_gpu", "rt_build_bvh_gpu_release", "rt_camera_view_params", "rt_version",
     "rt_debug_intersect", "rt_debug_math_eval", "rt_debug_phase_profile",
     "rt_flush",
     "rt_create_multi", "rt_destroy_multi", "rt_multi_count", "rt_multi_context", "rt_multi_resize", "rt_multi_upload_scene",
@@ -48,6 +48,7 @@ class HipApi(abi.CApi):
                                    C.POINTER(C.c_int), C.c_void_p, C.POINTER(abi.RtBvhStats)]),
         "build_bvh_gpu": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                     C.POINTER(C.c_int), C.c_void_p, C.POINTER(abi.RtBvhStats)]),
+        "build_bvh_gpu_release": (None, []),
         "debug_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
         "debug_math_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
         "debug_phase_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
