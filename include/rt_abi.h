@@ -336,7 +336,7 @@ int rt_build_bvh_gpu(int device_id, const float* verts, const float* normals, in
                      RtBVHNode* out_nodes, int* out_n_nodes,
                      RtTriangle* out_tris, RtBvhStats* out_stats);
 /* rt_build_bvh_gpu keeps its device scratch between calls of the same thread (a scene build calls it once per mesh;
- * at most 1 GiB is kept, larger builds free it on return).  This frees it now. */
+ * at most 4 GiB is kept, larger builds free it on return).  This frees it now. */
 void rt_build_bvh_gpu_release(void);
 /* RCM:183-190 UpdateCameraParams: fills viewParams from (fovDeg, aspect, focusDist). */
 int rt_camera_view_params(float fov_deg, float aspect, float focus_distance, float out_view_params[3]);

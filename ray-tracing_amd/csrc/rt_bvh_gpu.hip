@@ -142,12 +142,21 @@ __global__ void k_candidates(GNode* nodes, int first, int nActive, int quality, 
     counts[a] = nc > 0 ? (n.count + GB_CHUNK - 1) / GB_CHUNK : 0; /* sweep chunks of this node */
 }
 
-__global__ void k_chunk_map(GNode* nodes, int first, int nActive, const int* chunkBase, const int* counts, int* chunkNode)
+/* chunk -> node: chunkBase is the exclusive prefix sum of the nodes' chunk counts (non-decreasing); chunk c belongs to
+ * the LAST node whose base is <= c (nodes without chunks share their base with the next node).  One thread per chunk
+ * (the root of a 327k-triangle mesh has 640 of them; a thread per node walked them one by one). */
+__global__ void k_chunk_map(GNode* nodes, int first, int nActive, const int* chunkBase, int maxChunks, int* chunkNode)
 {
-    int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= nActive) return;
-    nodes[first + a].chunkBase = chunkBase[a];
-    for (int k = 0; k < counts[a]; k++) chunkNode[chunkBase[a] + k] = a;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nActive) nodes[first + c].chunkBase = chunkBase[c];
+    if (c >= maxChunks || c >= chunkBase[nActive]) return;
+    int lo = 0, hi = nActive - 1; /* find the largest a with chunkBase[a] <= c */
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (chunkBase[mid] <= c) lo = mid;
+        else hi = mid - 1;
+    }
+    chunkNode[c] = lo;
 }
 
 /* EvaluateSplit (BVH:253-311) over one chunk of one node: thread (candidate j, run s) scans its run of up to
@@ -211,44 +220,92 @@ __device__ __forceinline__ float node_cost(const float* mn, const float* mx, int
     return area * n;
 }
 
-/* per active node: combine the chunk partials in order, choose the split (BVH:200-208), decide (BVH:101) */
-__global__ void k_choose(GNode* nodes, int first, int nActive, int quality, const GCand* cands, const GBox* partial, const int* chunkCounts,
-                         GBox* chosen, int* splitFlag)
+/* per active node: combine the chunk partials in order, choose the split (BVH:200-208), decide (BVH:101).
+ * 16 x SEGS threads per node: thread (candidate j, segment s) appends its quarter (SEGS = 4) or all (SEGS = 1) of the
+ * node's chunks in order, the segments are appended in order, lane 0 of the group picks the first cheapest candidate.
+ * (One thread per node did all 16 candidates x up to 640 chunks alone: 60 % of the whole build's GPU time.) */
+__device__ __forceinline__ GBox box_shfl(const GBox& b, int srcLane)
 {
-    int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a == nActive) splitFlag[nActive] = 0;
-    if (a >= nActive) return;
+    GBox r;
+    for (int k = 0; k < 3; k++) {
+        r.lmn[k] = __shfl(b.lmn[k], srcLane, 64); r.lmx[k] = __shfl(b.lmx[k], srcLane, 64);
+        r.rmn[k] = __shfl(b.rmn[k], srcLane, 64); r.rmx[k] = __shfl(b.rmx[k], srcLane, 64);
+    }
+    r.nLeft = __shfl(b.nLeft, srcLane, 64);
+    return r;
+}
+template <int SEGS>
+__global__ void __launch_bounds__(256) k_choose(GNode* nodes, int first, int nActive, int quality, const GCand* cands, const GBox* partial, const int* chunkCounts,
+                                                GBox* chosen, int* splitFlag)
+{
+    constexpr int TPN = GB_NCAND * SEGS; /* threads per node: 16 or 64, a divisor of the wave size */
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gt == 0) splitFlag[nActive] = 0;
+    const int a0 = gt / TPN;
+    const bool valid = a0 < nActive;
+    const int a = valid ? a0 : 0; /* lanes past the end go through the motions (the shuffles below are wave-wide) */
+    const int lane = threadIdx.x & 63, group0 = lane & ~(TPN - 1);
+    const int j = lane & (GB_NCAND - 1), seg = (lane & (TPN - 1)) >> 4;
     GNode& n = nodes[first + a];
-    const int nc = n.nCand;
+    const int nc = n.nCand, count = n.count;
+    const bool mine = nc > 0 && (j < nc || j == GB_NCAND - 1);
+    GBox acc;
+    box_reset(acc);
+    if (mine) {
+        const int nChunks = chunkCounts[a];
+        const int per = (nChunks + SEGS - 1) / SEGS;
+        const int c0 = seg * per, c1 = (c0 + per < nChunks) ? c0 + per : nChunks;
+        for (int c = c0; c < c1; c++) {
+            const GBox p = partial[(size_t)(n.chunkBase + c) * GB_NCAND + j];
+            if (c == c0) acc = p;      /* the reference starts from the first triangle's values: box_reset's sentinels would also do, */
+            else box_append(acc, p);   /* but a copy keeps the bits of a chunk that is alone exactly as the sweep left them */
+        }
+    }
+    if (SEGS > 1) { /* later segments appended in order onto segment 0 (an empty segment appends sentinels: no change) */
+        for (int sgm = 1; sgm < SEGS; sgm++) {
+            const GBox o = box_shfl(acc, group0 + sgm * GB_NCAND + j);
+            const int oc = __shfl(mine ? 1 : 0, group0 + sgm * GB_NCAND + j, 64);
+            if (seg == 0 && mine && oc) {
+                const int nChunks = chunkCounts[a];
+                const int per = (nChunks + SEGS - 1) / SEGS;
+                if (sgm * per < nChunks) box_append(acc, o);
+            }
+        }
+    }
+    /* candidate costs in lanes (j, segment 0) */
+    float cj = GB_FMAX;
+    if (mine && j != GB_NCAND - 1) cj = node_cost(acc.lmn, acc.lmx, acc.nLeft) + node_cost(acc.rmn, acc.rmx, count - acc.nLeft);
     int best = -1;
     float cost = INFINITY; /* count <= 1: BVH:185 */
-    GBox bestBox, fallback;
-    box_reset(bestBox);
-    box_reset(fallback);
     if (nc > 0) {
-        float bestCost = GB_FMAX;
-        const int nChunks = chunkCounts[a];
-        for (int j = 0; j < GB_NCAND; j++) {
-            if (j >= nc && j != GB_NCAND - 1) continue;
-            GBox acc = partial[(size_t)n.chunkBase * GB_NCAND + j];
-            for (int c = 1; c < nChunks; c++) box_append(acc, partial[(size_t)(n.chunkBase + c) * GB_NCAND + j]);
-            if (j == GB_NCAND - 1) { fallback = acc; continue; }
-            float cj = node_cost(acc.lmn, acc.lmx, acc.nLeft) + node_cost(acc.rmn, acc.rmx, n.count - acc.nLeft);
-            if (quality == RT_BVH_QUALITY_LOW) { best = 0; cost = cj; bestBox = acc; break; }
-            if (cj < bestCost) { bestCost = cj; best = j; bestBox = acc; }
+        if (quality == RT_BVH_QUALITY_LOW) {
+            best = 0;
+            cost = __shfl(cj, group0, 64);
+        } else {
+            float bestCost = GB_FMAX;
+            for (int k = 0; k < GB_NCAND - 1; k++) { /* BVH:200-208: strict '<', the first of equal costs stays */
+                const float ck = __shfl(cj, group0 + k, 64);
+                if (k < nc && ck < bestCost) { bestCost = ck; best = k; }
+            }
+            cost = bestCost;
         }
-        if (quality != RT_BVH_QUALITY_LOW) cost = bestCost;
+    } else {
+        for (int k = 0; k < GB_NCAND - 1; k++) (void)__shfl(cj, group0 + k, 64); /* keep the wave's shuffles aligned */
     }
     const float sx = n.bmax[0] - n.bmin[0], sy = n.bmax[1] - n.bmin[1], sz = n.bmax[2] - n.bmin[2];
     float parentCost = 0;
-    if (n.count != 0) { float area = sx * sy + sx * sz + sy * sz; parentCost = area * n.count; }
+    if (count != 0) { float area = sx * sy + sx * sz + sy * sz; parentCost = area * count; }
     const bool split = cost < parentCost && n.depth < 32; /* BVH:101 */
-    splitFlag[a] = split ? 1 : 0;
-    n.left = -1;
-    if (split) {
-        if (best >= 0) { n.splitAxis = cands[(size_t)a * GB_NCAND + best].axis; n.splitPos = cands[(size_t)a * GB_NCAND + best].pos; chosen[a] = bestBox; }
-        else { n.splitAxis = 0; n.splitPos = 0.0f; chosen[a] = fallback; } /* bestSplitAxis/Pos stay (0, 0): BVH:204-205 */
-        n.nLeft = chosen[a].nLeft;
+    const int pick = best >= 0 ? best : GB_NCAND - 1;     /* bestSplitAxis/Pos stay (0, 0) when no candidate won: BVH:204-205 */
+    if (valid && seg == 0 && j == pick && split) chosen[a] = acc;
+    if (valid && seg == 0 && j == 0) {
+        splitFlag[a] = split ? 1 : 0;
+        n.left = -1;
+    }
+    if (valid && seg == 0 && j == pick && split) {
+        if (best >= 0) { n.splitAxis = cands[(size_t)a * GB_NCAND + best].axis; n.splitPos = cands[(size_t)a * GB_NCAND + best].pos; }
+        else { n.splitAxis = 0; n.splitPos = 0.0f; }
+        n.nLeft = acc.nLeft;
     }
 }
 
@@ -398,28 +455,42 @@ __global__ void k_number(GNode* nodes, int first, int count)
     l.preIdx = n.preIdx + 1;
     r.preIdx = n.preIdx + 1 + l.innerCount;
 }
+__device__ __forceinline__ int wave_add(int v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
+__device__ __forceinline__ int wave_max(int v) { for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; } return v; }
+__device__ __forceinline__ int wave_min(int v) { for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t < v ? t : v; } return v; }
 __global__ void k_emit(const GNode* nodes, int total, RtBVHNode* out, int* stats /* leafCount, depthSum, depthMax, depthMin, triMax, triMin, triSum */)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const GNode& n = nodes[i];
-    RtBVHNode o;
-    for (int k = 0; k < 3; k++) { o.boundsMin[k] = n.bmin[k]; o.boundsMax[k] = n.bmax[k]; }
-    if (n.left >= 0) {
-        o.startIndex = 1 + 2 * n.preIdx; /* BVH:165 */
-        o.triangleCount = i == 0 ? -1 : 0; /* the root keeps its constructor value (BVH:61) */
-    } else {
-        o.startIndex = n.start;
-        o.triangleCount = n.count;
-        atomicAdd(&stats[0], 1);
-        atomicAdd(&stats[1], n.depth);
-        atomicMax(&stats[2], n.depth);
-        atomicMin(&stats[3], n.depth);
-        atomicMax(&stats[4], n.count);
-        atomicMin(&stats[5], n.count);
-        atomicAdd(&stats[6], n.count);
+    int leaf = 0, depth = 0, cnt = 0;
+    if (i < total) {
+        const GNode& n = nodes[i];
+        RtBVHNode o;
+        for (int k = 0; k < 3; k++) { o.boundsMin[k] = n.bmin[k]; o.boundsMax[k] = n.bmax[k]; }
+        if (n.left >= 0) {
+            o.startIndex = 1 + 2 * n.preIdx; /* BVH:165 */
+            o.triangleCount = i == 0 ? -1 : 0; /* the root keeps its constructor value (BVH:61) */
+        } else {
+            o.startIndex = n.start;
+            o.triangleCount = n.count;
+            leaf = 1; depth = n.depth; cnt = n.count;
+        }
+        out[n.id] = o;
     }
-    out[n.id] = o;
+    /* BuildStats (BVH:557-575): one set of atomics per wave instead of seven per leaf on the same seven words */
+    const int leaves = wave_add(leaf);
+    if (leaves == 0) return;
+    const int dSum = wave_add(leaf ? depth : 0), tSum = wave_add(leaf ? cnt : 0);
+    const int dMax = wave_max(leaf ? depth : INT32_MIN), dMin = wave_min(leaf ? depth : INT32_MAX);
+    const int tMax = wave_max(leaf ? cnt : INT32_MIN), tMin = wave_min(leaf ? cnt : INT32_MAX);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&stats[0], leaves);
+        atomicAdd(&stats[1], dSum);
+        atomicMax(&stats[2], dMax);
+        atomicMin(&stats[3], dMin);
+        atomicMax(&stats[4], tMax);
+        atomicMin(&stats[5], tMin);
+        atomicAdd(&stats[6], tSum);
+    }
 }
 __global__ void k_tri_index(const GTri* tris, int ntri, int* out)
 {
@@ -459,7 +530,7 @@ static inline int blocks(size_t n, int t = 256) { return (int)((n + t - 1) / t);
 
 struct Pool { int device = -1; DevBuf b[22]; };
 static thread_local Pool g_pool;
-static const size_t GB_POOL_KEEP = (size_t)1 << 30; /* scratch kept between calls: at most 1 GiB (a 1M-triangle mesh needs ~0.6 GiB) */
+static const size_t GB_POOL_KEEP = (size_t)4 << 30; /* scratch kept between calls: at most 4 GiB of the 288 (a 1.3M-triangle mesh needs ~1.5 GiB) */
 
 static void pool_release()
 {
@@ -479,8 +550,6 @@ static int build_impl(int device, const float* verts, const float* normals, int 
     if (!verts || !normals || !indices || !out_nodes || !out_n_nodes || !out_tris || n_verts < 0 || n_indices < 0 || n_indices % 3)
         return RT_ERR_INVALID_ARG;
     if (quality != RT_BVH_QUALITY_LOW && quality != RT_BVH_QUALITY_HIGH && quality != RT_BVH_QUALITY_DISABLED) return RT_ERR_INVALID_ARG;
-    for (int i = 0; i < n_indices; i++)
-        if (indices[i] < 0 || indices[i] >= n_verts) return RT_ERR_INVALID_ARG;
     auto t0 = std::chrono::steady_clock::now();
     const bool dbg = getenv("RT_BVH_DEBUG") != nullptr;
     auto lap = [&](const char* what) {
@@ -492,21 +561,80 @@ static int build_impl(int device, const float* verts, const float* normals, int 
     GB_TRY(hipSetDevice(device));
     const int ntri = n_indices / 3;
 
-    /* root bounds: BVH:53-58, in triangle order (host: one pass over the vertices of the indexed triangles) */
+    /* index validation + root bounds (BVH:53-58, in triangle order): ordered blocks of triangles on a few host threads,
+     * the blocks' boxes appended in order with the same strict comparisons (the first of equal values stays) */
     float rmn[3] = {GB_FMAX, GB_FMAX, GB_FMAX}, rmx[3] = {-GB_FMAX, -GB_FMAX, -GB_FMAX};
-    for (int t = 0; t < ntri; t++) {
-        const float* a = verts + 3 * indices[3 * t], * b = verts + 3 * indices[3 * t + 1], * c = verts + 3 * indices[3 * t + 2];
-        for (int k = 0; k < 3; k++) {
-            float mn = a[k] < b[k] ? (a[k] < c[k] ? a[k] : c[k]) : (b[k] < c[k] ? b[k] : c[k]);
-            float mx = a[k] > b[k] ? (a[k] > c[k] ? a[k] : c[k]) : (b[k] > c[k] ? b[k] : c[k]);
-            if (mn < rmn[k]) rmn[k] = mn;
-            if (mx > rmx[k]) rmx[k] = mx;
+    {
+        unsigned hc = std::thread::hardware_concurrency();
+        int nth = hc ? (int)(hc > 8 ? 8 : hc) : 1;
+        if (nth > ntri / 16384) nth = ntri / 16384;
+        if (nth < 1) nth = 1;
+        struct Part { float mn[3], mx[3]; bool bad; };
+        std::vector<Part> parts(nth);
+        auto scan = [&](int k, int b0, int e0) {
+            Part& P = parts[k];
+            for (int d = 0; d < 3; d++) { P.mn[d] = GB_FMAX; P.mx[d] = -GB_FMAX; }
+            P.bad = false;
+            for (int t = b0; t < e0; t++) {
+                const int ia = indices[3 * t], ib = indices[3 * t + 1], ic = indices[3 * t + 2];
+                if (ia < 0 || ia >= n_verts || ib < 0 || ib >= n_verts || ic < 0 || ic >= n_verts) { P.bad = true; return; }
+                const float* a = verts + 3 * ia, * b = verts + 3 * ib, * c = verts + 3 * ic;
+                for (int d = 0; d < 3; d++) {
+                    float mn = a[d] < b[d] ? (a[d] < c[d] ? a[d] : c[d]) : (b[d] < c[d] ? b[d] : c[d]);
+                    float mx = a[d] > b[d] ? (a[d] > c[d] ? a[d] : c[d]) : (b[d] > c[d] ? b[d] : c[d]);
+                    if (mn < P.mn[d]) P.mn[d] = mn;
+                    if (mx > P.mx[d]) P.mx[d] = mx;
+                }
+            }
+        };
+        if (nth == 1) scan(0, 0, ntri);
+        else {
+            std::vector<std::thread> th;
+            for (int k = 0; k < nth; k++) th.emplace_back(scan, k, (int)((long long)ntri * k / nth), (int)((long long)ntri * (k + 1) / nth));
+            for (auto& t : th) t.join();
+        }
+        for (int k = 0; k < nth; k++) {
+            if (parts[k].bad) return RT_ERR_INVALID_ARG;
+            for (int d = 0; d < 3; d++) {
+                if (parts[k].mn[d] < rmn[d]) rmn[d] = parts[k].mn[d];
+                if (parts[k].mx[d] > rmx[d]) rmx[d] = parts[k].mx[d];
+            }
         }
     }
 
     lap("validate + root box");
     std::vector<int> order(ntri);
     std::vector<RtBVHNode> nodesOut;
+    /* BVH:69-80: triangles in leaf order with vertex normals — host threads, started as soon as the order is known so that
+     * they run while the node array is still on its way back from the device */
+    std::vector<std::thread> gatherThreads;
+    bool gatherStarted = false;
+    auto start_gather = [&]() {
+        gatherStarted = true;
+        unsigned hc = std::thread::hardware_concurrency();
+        int threads = hc ? (int)(hc > 16 ? 16 : hc) : 1;
+        if (threads > ntri / 8192) threads = ntri / 8192;
+        if (threads < 1) threads = 1;
+        const int* ord = order.data();
+        auto fill = [=](int b0, int e0) {
+            for (int i = b0; i < e0; i++) {
+                const int b = ord[i];
+                RtTriangle& t = out_tris[i];
+                for (int k = 0; k < 3; k++) {
+                    t.posA[k] = verts[3 * indices[b + 0] + k];
+                    t.posB[k] = verts[3 * indices[b + 1] + k];
+                    t.posC[k] = verts[3 * indices[b + 2] + k];
+                    t.normA[k] = normals[3 * indices[b + 0] + k];
+                    t.normB[k] = normals[3 * indices[b + 1] + k];
+                    t.normC[k] = normals[3 * indices[b + 2] + k];
+                }
+            }
+        };
+        if (threads == 1) fill(0, ntri);
+        else
+            for (int t = 0; t < threads; t++) gatherThreads.emplace_back(fill, (int)((long long)ntri * t / threads), (int)((long long)ntri * (t + 1) / threads));
+    };
+    struct Joiner { std::vector<std::thread>& v; ~Joiner() { for (auto& t : v) if (t.joinable()) t.join(); } } joiner{gatherThreads}; /* every return path */
     int statsH[7] = {0, 0, 0, INT32_MAX, 0, INT32_MAX, 0};
     if (quality == RT_BVH_QUALITY_DISABLED || ntri == 0) { /* BVH:62-66 (and the empty mesh: Split makes the root a leaf) */
         RtBVHNode root;
@@ -577,9 +705,12 @@ static int build_impl(int device, const float* verts, const float* normals, int 
                 int* chunkNode = bChunkNode.get<int>(maxChunks);
                 GBox* partial = bPartial.get<GBox>((size_t)maxChunks * GB_NCAND);
                 if (!chunkNode || !partial) return RT_ERR_OOM;
-                hipLaunchKernelGGL(k_chunk_map, dim3(blocks(nActive)), dim3(256), 0, 0, nodes, first, nActive, base, counts, chunkNode);
+                hipLaunchKernelGGL(k_chunk_map, dim3(blocks(maxChunks > nActive ? maxChunks : nActive)), dim3(256), 0, 0, nodes, first, nActive, base, maxChunks, chunkNode);
                 hipLaunchKernelGGL(k_sweep, dim3(maxChunks), dim3(64), 0, 0, nodes, first, chunkNode, base + nActive, cands, trisA, partial);
-                hipLaunchKernelGGL(k_choose, dim3(blocks(nActive + 1)), dim3(256), 0, 0, nodes, first, nActive, quality, cands, partial, counts, chosen, splitFlag);
+                if (nActive <= 8192) /* few, possibly huge nodes: 64 threads each */
+                    hipLaunchKernelGGL(k_choose<4>, dim3(blocks((size_t)nActive * 64)), dim3(256), 0, 0, nodes, first, nActive, quality, cands, partial, counts, chosen, splitFlag);
+                else
+                    hipLaunchKernelGGL(k_choose<1>, dim3(blocks((size_t)nActive * 16)), dim3(256), 0, 0, nodes, first, nActive, quality, cands, partial, counts, chosen, splitFlag);
             }
             tb = 0;
             hipcub::DeviceScan::ExclusiveSum(nullptr, tb, splitFlag, splitRank, nActive + 1);
@@ -627,8 +758,9 @@ static int build_impl(int device, const float* verts, const float* normals, int 
         hipLaunchKernelGGL(k_tri_index, dim3(blocks(ntri)), dim3(256), 0, 0, trisA, ntri, S);
         GB_TRY(hipGetLastError());
         nodesOut.resize(total);
-        GB_TRY(hipMemcpy(nodesOut.data(), dOut, sizeof(RtBVHNode) * (size_t)total, hipMemcpyDeviceToHost));
         GB_TRY(hipMemcpy(order.data(), S, sizeof(int) * (size_t)ntri, hipMemcpyDeviceToHost));
+        start_gather();
+        GB_TRY(hipMemcpy(nodesOut.data(), dOut, sizeof(RtBVHNode) * (size_t)total, hipMemcpyDeviceToHost));
         GB_TRY(hipMemcpy(statsH, misc, sizeof(statsH), hipMemcpyDeviceToHost));
         lap("numbering + readback");
     }
@@ -636,35 +768,11 @@ static int build_impl(int device, const float* verts, const float* normals, int 
         *out_n_nodes = 0;
         return RT_ERR_SCENE;
     }
-    {   /* BVH:69-80: triangles in leaf order with vertex normals */
-        unsigned hc = std::thread::hardware_concurrency();
-        int threads = hc ? (int)(hc > 16 ? 16 : hc) : 1;
-        if (threads > ntri / 8192) threads = ntri / 8192;
-        if (threads < 1) threads = 1;
-        const int* ord = order.data();
-        auto fill = [=](int b0, int e0) {
-            for (int i = b0; i < e0; i++) {
-                const int b = ord[i];
-                RtTriangle& t = out_tris[i];
-                for (int k = 0; k < 3; k++) {
-                    t.posA[k] = verts[3 * indices[b + 0] + k];
-                    t.posB[k] = verts[3 * indices[b + 1] + k];
-                    t.posC[k] = verts[3 * indices[b + 2] + k];
-                    t.normA[k] = normals[3 * indices[b + 0] + k];
-                    t.normB[k] = normals[3 * indices[b + 1] + k];
-                    t.normC[k] = normals[3 * indices[b + 2] + k];
-                }
-            }
-        };
-        if (threads == 1) fill(0, ntri);
-        else {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < threads; t++) pool.emplace_back(fill, (int)((long long)ntri * t / threads), (int)((long long)ntri * (t + 1) / threads));
-            for (auto& th : pool) th.join();
-        }
-    }
+    if (!gatherStarted) start_gather();
     memcpy(out_nodes, nodesOut.data(), nodesOut.size() * sizeof(RtBVHNode));
     *out_n_nodes = (int)nodesOut.size();
+    for (auto& t : gatherThreads) t.join();
+    gatherThreads.clear();
     lap("triangle gather");
     if (out_stats) {
         memset(out_stats, 0, sizeof(*out_stats));
