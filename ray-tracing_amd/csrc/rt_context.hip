@@ -1160,6 +1160,7 @@ static void fill_args(RtContext* ctx, int frame0, int nFrames, KArgs& a)
         const bool noNegZero = rt_f2u(o.x) != 0x80000000u && rt_f2u(o.y) != 0x80000000u && rt_f2u(o.z) != 0x80000000u;
         a.raygenNoDefocus = (a.defocus == 0.0f && fin && noNegZero && std::isfinite(a.rcpW)) ? 1 : 0;
     }
+    a.debugCoherent = getenv("RT_DEBUG_COHERENT") && atoi(getenv("RT_DEBUG_COHERENT")) ? 1 : 0;
     a.counters = ctx->dCounters;
 }
 

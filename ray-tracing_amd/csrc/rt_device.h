@@ -134,6 +134,9 @@ struct KArgs {
     float rcpSpp;                /* 1 / NumRaysPerPixel   — RC:581 */
     int32_t suspendNum;          /* traverse() is left once active <= entered * suspendNum / 8 lanes are still traversing */
     int32_t raygenNoDefocus;     /* defocusStrength == 0, camera matrix finite, no component of the camera origin is -0 */
+    int32_t debugCoherent;       /* MEASUREMENT ONLY (RT_DEBUG_COHERENT=1): every idle lane of a wave is handed the SAME pixel, so all 64
+                                  * lanes run identical chains — the rate of a wave whose rays never diverge, i.e. the ceiling of any
+                                  * regrouping / compaction scheme.  The image is still correct (64 lanes write the same values). */
     /* counters: RT_COUNTER_SLOTS x RT_COUNTER_FIELDS u64 */
     unsigned long long* counters;
     /* persistent waves: this launch renders launchTiles tiles; its queue position q is entry

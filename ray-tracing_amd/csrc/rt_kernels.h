@@ -841,7 +841,11 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                 if (c.tileOrder) next = (int)c.tileOrder[next];
                 RT_SET_POOL(c, next);
             }
+#ifdef RT_COHERENT_EXPERIMENT /* measurement build only (make coherent): see KArgs::debugCoherent */
+            const int rank = c.debugCoherent ? 0 : __popcll(idle & ((1ull << lane) - 1ull));
+#else
             const int rank = __popcll(idle & ((1ull << lane) - 1ull));
+#endif
             const int avail = 64 - poolPos;
             if (laneDone && rank < avail) {
                 phase_mark<STATS>(st, PH_REFILL);
@@ -874,7 +878,11 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     laneDone = false;
                 }
             }
+#ifdef RT_COHERENT_EXPERIMENT
+            const int wanted = c.debugCoherent ? 1 : __popcll(idle);
+#else
             const int wanted = __popcll(idle);
+#endif
             poolPos += wanted < avail ? wanted : avail;
             idle = __ballot(laneDone);
         }
