@@ -387,8 +387,10 @@ def main():
     for _ in range(args.steps):
         tracer.render_frame()
     tracer.timer_end()
-    barrier()
-    t1 = time.perf_counter()
+    tracer.synchronize()          # this rank's K steps are done ...
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()      # ... at t1; the job's time is the MAX over ranks of t1 - t0 (taken below), so the closing
+    barrier()                     # barrier brackets the region without adding the collective's own latency to every rank
     accumulated[0] += args.steps
     timed = tracer.counters()
     elapsed = t1 - t0
