@@ -188,3 +188,25 @@ def test_gpu_builder_big_meshes_and_refusal(pkg, api):
     with pytest.raises(pkg.abi.RtError) as e:
         api.build_bvh_arrays_gpu(v, np.tile([[0, 1, 0]], (9, 1)), np.arange(9, dtype=np.int32), 1)
     assert e.value.status == pkg.abi.RT_ERR_SCENE
+
+
+@pytest.mark.gpu
+def test_gpu_builder_leaves_the_callers_device_state_alone(pkg, api):
+    """rt_build_bvh_gpu keeps its scratch between calls; rt_build_bvh_gpu_release frees it, a build after that works
+    again, bad input leaves 0 nodes behind, and every error path reports n_nodes = 0."""
+    import ctypes as C
+    mesh = pkg.meshes.icosphere(3, 1.0, 2)
+    n0, t0, _ = api.build_bvh_arrays(mesh.vertices, mesh.normals, mesh.triangles, 1)
+    for _ in range(2):
+        n1, t1, _ = api.build_bvh_arrays_gpu(mesh.vertices, mesh.normals, mesh.triangles, 1)
+        assert n0.tobytes() == n1.tobytes() and t0.tobytes() == t1.tobytes()
+        api.build_bvh_gpu_release()
+    # an index out of range: refused, n_nodes stays 0
+    bad = mesh.triangles.copy()
+    bad[5] = len(mesh.vertices) + 3
+    nodes = np.zeros(2 * len(bad) // 3, dtype=pkg.abi.node_dtype)
+    tris = np.zeros(len(bad) // 3, dtype=pkg.abi.triangle_dtype)
+    nn = C.c_int(77)
+    rc = api.build_bvh_gpu(0, mesh.vertices.ctypes.data, mesh.normals.ctypes.data, len(mesh.vertices), bad.ctypes.data, len(bad), 1,
+                           nodes.ctypes.data, C.byref(nn), tris.ctypes.data, None)
+    assert rc == pkg.abi.RT_ERR_INVALID_ARG and nn.value == 0

@@ -400,6 +400,50 @@ def test_multi_device_entry_equals_single_context(pkg, api, n):
     assert ca["segments"] == cb["segments"] and cb["pixelFrames"] == 3 * 120 * 100
 
 
+def test_multi_device_upload_paths_and_held_frames(pkg, api, monkeypatch):
+    """rt_multi_upload_scene prepares the scene once and fills contexts 1.. with device-to-device copies of context 0's
+    arrays (RT_MULTI_PEER_UPLOAD=0: every context from the host): same image either way.  And frames a context holds back
+    (rt_render_frame calls that arrive while the GPU is busy) are launched on every device by the gather itself."""
+    images = []
+    for peer in ("1", "0"):
+        monkeypatch.setenv("RT_MULTI_PEER_UPLOAD", peer)
+        multi = api.create_multi_tracer([0, 0, 0])
+        sc = pkg.scenes.get(4, subdivisions=3)
+        mgr = sc.make_manager(multi, api, 96, 56)
+        mgr.OnEnable(renderSeed=9)
+        for _ in range(7):          # back-to-back single-frame requests: some are held back in every context
+            mgr.RenderFrame()
+        images.append(multi.read_accumulated())   # no synchronise before: the gather has to flush all three devices
+        assert multi.last_gather_ms() > 0
+        multi.close()
+    assert bits_equal(images[0], images[1])
+    assert np.all(images[0][..., 3] == 7)
+    single = api.create_tracer(0)
+    a, _ = render(pkg, api, single, 4, 96, 56, 7, seed=9, scene_kw={"subdivisions": 3})
+    single.close()
+    assert bits_equal(images[0], a)
+
+
+def test_direct_target_readers_see_every_requested_frame(pkg, api):
+    """A host that reads the render targets itself after its own device synchronise: rt_get_render_targets launches the
+    frames rt_render_frame still held back (they are launched lazily), so that synchronise covers them."""
+    import ctypes as C
+    tr = api.create_tracer(0)
+    sc = pkg.scenes.get(2)
+    mgr = sc.make_manager(tr, api, 256, 144)
+    mgr.OnEnable(renderSeed=2)
+    for _ in range(12):
+        mgr.RenderFrame()
+    f, a = tr.render_targets()          # flushes
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipDeviceSynchronize() == 0
+    host = np.zeros((144, 256, 4), dtype=np.float32)
+    assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(a), C.c_size_t(host.nbytes), C.c_int(2)) == 0   # hipMemcpyDeviceToHost
+    assert np.all(host[..., 3] == 12)
+    assert bits_equal(host, tr.read_accumulated())
+    tr.close()
+
+
 # ------------------------------------------------------------------ scheduling must not change results
 @pytest.mark.parametrize("grid", ["1", "3", "1000000"])
 def test_persistent_grid_size_does_not_change_results(pkg, api, orc, grid, monkeypatch):
