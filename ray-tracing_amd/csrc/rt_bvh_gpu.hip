@@ -604,7 +604,9 @@ static int build_impl(int device, const float* verts, const float* normals, int 
 
     lap("validate + root box");
     std::vector<int> order(ntri);
-    std::vector<RtBVHNode> nodesOut;
+    std::vector<RtBVHNode> nodesOut; /* host-made trees (no BVH / empty mesh) */
+    size_t nNodesOut = 0;            /* nodes of the result, wherever they were written */
+    bool nodesInPlace = false;       /* the device tree was copied straight into out_nodes (no staging copy of ~21 MB at 327k triangles) */
     /* BVH:69-80: triangles in leaf order with vertex normals — host threads, started as soon as the order is known so that
      * they run while the node array is still on its way back from the device */
     std::vector<std::thread> gatherThreads;
@@ -757,27 +759,30 @@ static int build_impl(int device, const float* verts, const float* normals, int 
         hipLaunchKernelGGL(k_emit, dim3(blocks(total)), dim3(256), 0, 0, nodes, total, dOut, misc);
         hipLaunchKernelGGL(k_tri_index, dim3(blocks(ntri)), dim3(256), 0, 0, trisA, ntri, S);
         GB_TRY(hipGetLastError());
-        nodesOut.resize(total);
+        if ((size_t)total > 2 * (size_t)(ntri > 0 ? ntri : 1)) return RT_ERR_SCENE; /* out_nodes holds 2 * ntri nodes; as rt_build_bvh */
         GB_TRY(hipMemcpy(order.data(), S, sizeof(int) * (size_t)ntri, hipMemcpyDeviceToHost));
         start_gather();
-        GB_TRY(hipMemcpy(nodesOut.data(), dOut, sizeof(RtBVHNode) * (size_t)total, hipMemcpyDeviceToHost));
+        GB_TRY(hipMemcpy(out_nodes, dOut, sizeof(RtBVHNode) * (size_t)total, hipMemcpyDeviceToHost));
+        nodesInPlace = true;
+        nNodesOut = (size_t)total;
         GB_TRY(hipMemcpy(statsH, misc, sizeof(statsH), hipMemcpyDeviceToHost));
         lap("numbering + readback");
     }
-    if (nodesOut.size() > 2 * (size_t)(ntri > 0 ? ntri : 1) || (ntri > 0 && statsH[0] > 0 && statsH[5] == 0)) { /* as rt_build_bvh */
+    if (!nodesInPlace) nNodesOut = nodesOut.size();
+    if (nNodesOut > 2 * (size_t)(ntri > 0 ? ntri : 1) || (ntri > 0 && statsH[0] > 0 && statsH[5] == 0)) { /* as rt_build_bvh */
         *out_n_nodes = 0;
         return RT_ERR_SCENE;
     }
     if (!gatherStarted) start_gather();
-    memcpy(out_nodes, nodesOut.data(), nodesOut.size() * sizeof(RtBVHNode));
-    *out_n_nodes = (int)nodesOut.size();
+    if (!nodesInPlace) memcpy(out_nodes, nodesOut.data(), nodesOut.size() * sizeof(RtBVHNode));
+    *out_n_nodes = (int)nNodesOut;
     for (auto& t : gatherThreads) t.join();
     gatherThreads.clear();
     lap("triangle gather");
     if (out_stats) {
         memset(out_stats, 0, sizeof(*out_stats));
         out_stats->triangleCount = statsH[6];
-        out_stats->totalNodeCount = (int)nodesOut.size() - (quality == RT_BVH_QUALITY_DISABLED ? 1 : 0);
+        out_stats->totalNodeCount = (int)nNodesOut - (quality == RT_BVH_QUALITY_DISABLED ? 1 : 0);
         out_stats->leafNodeCount = statsH[0];
         out_stats->leafDepthMax = statsH[2];
         out_stats->leafDepthMin = statsH[3];
