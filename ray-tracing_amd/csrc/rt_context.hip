@@ -1201,7 +1201,7 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         if (ctx->pxColdWaves < waves) { /* kernels in flight use the old block: it is freed stream-ordered, not now */
             HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
             hipFree(ctx->dPxCold); ctx->dPxCold = nullptr; ctx->pxColdWaves = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->dPxCold, (size_t)2 * waves * RT_WAVE * 2 * sizeof(float4)));
+            HIP_TRY(ctx, hipMalloc(&ctx->dPxCold, (size_t)2 * waves * RT_COLD_STRIDE_BYTES));
             ctx->pxColdWaves = waves;
         }
     }
@@ -1333,7 +1333,7 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         const long long items = (long long)partTiles * a.frameGroups;
         int grid = (int)(resident < items ? resident : items);
         if (ctx->gridOverride > 0) grid = (int)(ctx->gridOverride < items ? ctx->gridOverride : items);
-        a.pxCold = (float4*)ctx->dPxCold + (size_t)p * ctx->pxColdWaves * RT_WAVE * 2;
+        a.pxCold = (float4*)((char*)ctx->dPxCold + (size_t)p * ctx->pxColdWaves * RT_COLD_STRIDE_BYTES);
         a.launchTiles = partTiles;
         a.launchItems = (int)items;
         a.orderOffset = p;

@@ -31,6 +31,12 @@
 #define RT_COUNTER_SLOTS 1024        /* counters are spread over slots to avoid same-address atomics */
 #define RT_PIXEL_FIELDS 4
 #define RT_N_PHASES 12
+/* bytes of a wave's record in KArgs::pxCold: two float4 per lane (+ the traversal stack in the RT_GLOBAL_STACK experiment) */
+#ifdef RT_GLOBAL_STACK
+#define RT_COLD_STRIDE_BYTES (2 * RT_WAVE * 16 + RT_STACK_DEPTH * RT_WAVE * 4)
+#else
+#define RT_COLD_STRIDE_BYTES (2 * RT_WAVE * 16)
+#endif
 #define RT_COUNTER_FIELDS (8 + 2 * RT_N_PHASES)
 
 /* node codes: bit31 = leaf.  leaf: [30:24] = triangle count (1..127), [23:0] = first

@@ -715,7 +715,11 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
 {
     extern __shared__ uint32_t s_stack[];
     const int lane = threadIdx.x;
+#ifdef RT_GLOBAL_STACK /* EXPERIMENT (make global-stack): the traversal stack in an L2-resident per-wave array instead of LDS — what a pop costs there */
+    uint32_t* stackBase = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(cold_args().pxCold) + (size_t)blockIdx.x * RT_COLD_STRIDE_BYTES + 2 * RT_WAVE * 16) + lane;
+#else
     uint32_t* stackBase = &s_stack[lane];
+#endif
 
     /* Persistent wave: the wave starts on tile blockIdx.x and, whenever lanes run out of
      * work (their pixel is finished), hands them the next unassigned pixels of its current
@@ -793,7 +797,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
      * its records live in LDS too ([2][64] float4 after the pixel fields) — no record traffic to memory at all, and the
      * camera-ray phase reads its focus point back at LDS latency. */
 #define PX_COLD(c) (FLAT ? reinterpret_cast<float4*>(__builtin_assume_aligned(pxu - lane + RT_PIXEL_FIELDS * RT_WAVE, 16)) + lane \
-                         : ((c).pxCold + (size_t)blockIdx.x * (2 * RT_WAVE) + (size_t)lane)) /* [wave][2][lane]: a wave's store covers 1 KB without gaps */
+                         : ((c).pxCold + (size_t)blockIdx.x * (RT_COLD_STRIDE_BYTES / 16) + (size_t)lane)) /* [wave][2][lane]: a wave's store covers 1 KB without gaps */
 #define PXU(k) pxu[(k) * RT_WAVE]
 #define PXF(k) pxf[(k) * RT_WAVE]
     uint32_t rng = 0;
