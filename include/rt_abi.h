@@ -289,6 +289,11 @@ int rt_multi_synchronize(RtMulti* m);
  * copied to pinned host memory on its own stream (all devices concurrently) and scattered to its global rows. */
 int rt_gather_accumulated(RtMulti* m, float* rgba, size_t bytes);
 int rt_gather_frame(RtMulti* m, float* rgba, size_t bytes);
+/* The same gather into DEVICE memory of context `root`'s GPU (H*W*16 bytes, e.g. a display or post-processing buffer):
+ * every context's strips are copied device to device into their global rows on that context's own stream — xGMI between
+ * different GPUs, all sources at once, no host memory in between.  Synchronises every context. */
+int rt_gather_accumulated_to_device(RtMulti* m, int root, void* d_rgba, size_t bytes);
+int rt_gather_frame_to_device(RtMulti* m, int root, void* d_rgba, size_t bytes);
 /* Wall time of the last gather (copies + scatter, after the flush), milliseconds. */
 double rt_multi_last_gather_ms(const RtMulti* m);
 /* Sum of the contexts' counters (gpuMs: the maximum). */

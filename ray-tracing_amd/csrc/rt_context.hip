@@ -1864,6 +1864,48 @@ static int multi_gather(RtMulti* m, float* rgba, size_t bytes, bool accumulated)
     m->lastGatherMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;
 }
+/* The gather with a DEVICE destination: every context's strips go straight into their global rows of an image on the
+ * device of context `root` — device-to-device copies on each source context's own stream (ordered after its frames; xGMI
+ * between different GPUs, all sources concurrently), no host memory in between.  For hosts that display or post-process on
+ * one of the GPUs. */
+static int multi_gather_device(RtMulti* m, int root, void* d_rgba, size_t bytes, bool accumulated)
+{
+    if (!m || m->ctx.empty()) return fail(nullptr, RT_ERR_INVALID_ARG, "null multi context");
+    RtContext* c0 = m->ctx[0];
+    if (root < 0 || root >= (int)m->ctx.size()) return fail(c0, RT_ERR_INVALID_ARG, "rt_gather_*_to_device: root %d out of range", root);
+    const int W = c0->W, H = c0->H;
+    if (!d_rgba || bytes != (size_t)W * H * 16) return fail(c0, RT_ERR_INVALID_ARG, "rt_gather_*_to_device: bytes %zu != H*W*16 = %zu", bytes, (size_t)W * H * 16);
+    const size_t rowBytes = (size_t)W * 16;
+    const int rootDev = m->ctx[root]->device;
+    int rc = multi_flush_all(m);
+    if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (RtContext* c : m->ctx) {
+        if (c->W != W || c->H != H) return fail(c0, RT_ERR_STATE, "rt_gather: contexts disagree on the resolution");
+        const int rows = c->localRows;
+        if (!rows) continue;
+        const char* src = (const char*)(accumulated ? (c->boundAccum ? c->boundAccum : c->ownAccum) : (c->boundFrame ? c->boundFrame : c->ownFrame));
+        HIP_TRY(c, hipSetDevice(c->device));
+        hipStream_t st = joined(c);
+        for (int l = 0; l < rows;) { /* a strip's rows are contiguous in the packed tile and in the image */
+            const int g = rt_local_to_global_row(c, l);
+            int run = c->stripRows - (g % c->stripRows);
+            if (run > rows - l) run = rows - l;
+            HIP_TRY(c, hipMemcpyPeerAsync((char*)d_rgba + (size_t)g * rowBytes, rootDev, src + (size_t)l * rowBytes, c->device, (size_t)run * rowBytes, st));
+            l += run;
+        }
+    }
+    for (RtContext* c : m->ctx) {
+        if (!c->localRows) continue;
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        flush_timer(c);
+    }
+    m->lastGatherMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+int rt_gather_accumulated_to_device(RtMulti* m, int root, void* d_rgba, size_t bytes) { return multi_gather_device(m, root, d_rgba, bytes, true); }
+int rt_gather_frame_to_device(RtMulti* m, int root, void* d_rgba, size_t bytes) { return multi_gather_device(m, root, d_rgba, bytes, false); }
 int rt_gather_accumulated(RtMulti* m, float* rgba, size_t bytes) { return multi_gather(m, rgba, bytes, true); }
 int rt_gather_frame(RtMulti* m, float* rgba, size_t bytes) { return multi_gather(m, rgba, bytes, false); }
 

@@ -424,6 +424,36 @@ def test_multi_device_upload_paths_and_held_frames(pkg, api, monkeypatch):
     assert bits_equal(images[0], a)
 
 
+def test_gather_into_device_memory_equals_the_host_gather(pkg, api):
+    """rt_gather_accumulated_to_device / rt_gather_frame_to_device: strips copied device to device into their global rows of
+    an image on the root context's GPU == the host gather, for every root.  (Device memory through the HIP runtime the
+    library already loaded — importing torch after it would bring a second runtime into the process.)"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    multi = api.create_multi_tracer([0, 0, 0, 0, 0])
+    sc = pkg.scenes.get(3)
+    mgr = sc.make_manager(multi, api, 152, 101)      # 13 strips, the last one ragged: 5 contexts get 3/3/3/2/2 strips
+    mgr.OnEnable(renderSeed=4)
+    for _ in range(5):
+        mgr.RenderFrame()
+    nbytes = 101 * 152 * 16
+    d = C.c_void_p()
+    assert hip.hipMalloc(C.byref(d), C.c_size_t(nbytes)) == 0
+    try:
+        for root in (0, 3):
+            for gather, read in ((multi.gather_accumulated_to_device, multi.read_accumulated), (multi.gather_frame_to_device, multi.read_frame)):
+                assert hip.hipMemset(d, 0xff, C.c_size_t(nbytes)) == 0 and hip.hipDeviceSynchronize() == 0
+                gather(root, d, nbytes)
+                host = np.zeros((101, 152, 4), dtype=np.float32)
+                assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), d, C.c_size_t(nbytes), C.c_int(2)) == 0
+                assert bits_equal(host, read())
+        assert np.all(multi.read_accumulated()[..., 3] == 5)
+        assert multi.last_gather_ms() > 0
+    finally:
+        hip.hipFree(d)
+        multi.close()
+
+
 def test_direct_target_readers_see_every_requested_frame(pkg, api):
     """A host that reads the render targets itself after its own device synchronise: rt_get_render_targets launches the
     frames rt_render_frame still held back (they are launched lazily), so that synchronise covers them."""
