@@ -46,6 +46,9 @@
 #ifndef RT_MIN_WAVES_PER_SIMD
 #define RT_MIN_WAVES_PER_SIMD 6
 #endif
+#ifndef RT_MIN_WAVES_PER_SIMD_MANY
+#define RT_MIN_WAVES_PER_SIMD_MANY RT_MIN_WAVES_PER_SIMD /* the > 64-model instantiation (measured at 5 as well: see DESIGN.md §4.12) */
+#endif
 #ifndef RT_MIN_WAVES_PER_SIMD_FLAT
 #define RT_MIN_WAVES_PER_SIMD_FLAT 8
 #endif
@@ -1110,12 +1113,12 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
 /* MANY: scenes with more than 64 models (two-level filter, candidate masks extended into LDS) — a separate
  * instantiation so that the common case keeps its registers */
 template <bool STATS, bool FLAT, bool MANY = false>
-__global__ void __launch_bounds__(RT_WAVE, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : RT_MIN_WAVES_PER_SIMD) rt_trace_kernel(const KArgs a)
+__global__ void __launch_bounds__(RT_WAVE, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : MANY ? RT_MIN_WAVES_PER_SIMD_MANY : RT_MIN_WAVES_PER_SIMD) rt_trace_kernel(const KArgs a)
 {
     trace_body<STATS, FLAT, MANY>(a);
 }
 template <bool STATS, bool FLAT, bool MANY = false>
-__global__ void __launch_bounds__(RT_WAVE, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : RT_MIN_WAVES_PER_SIMD) rt_trace_half_kernel(const KArgs a)
+__global__ void __launch_bounds__(RT_WAVE, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : MANY ? RT_MIN_WAVES_PER_SIMD_MANY : RT_MIN_WAVES_PER_SIMD) rt_trace_half_kernel(const KArgs a)
 {
     trace_body<STATS, FLAT, MANY>(a);
 }
