@@ -1,0 +1,70 @@
+// Issue cost of single VALU instructions on gfx950, pinned with inline asm (8 independent dependent-chains per lane,
+// 8 waves per SIMD resident): cycles per wave64 instruction per SIMD at the clock measured by wall_clock64 / events.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#define N_ITER 4096
+#define REP8(OP) OP(a0) OP(a1) OP(a2) OP(a3) OP(a4) OP(a5) OP(a6) OP(a7)
+#define K(NAME, ASM)                                                                                                   \
+    __global__ void __launch_bounds__(256) k_##NAME(float* out, float seed)                                            \
+    {                                                                                                                  \
+        float a0 = seed + threadIdx.x, a1 = a0 * 1.1f, a2 = a0 * 1.2f, a3 = a0 * 1.3f, a4 = a0 * 1.4f, a5 = a0 * 1.5f, a6 = a0 * 1.6f, a7 = a0 * 1.7f; \
+        float c = seed * 0.999f, d = seed * 1.001f;                                                                    \
+        unsigned long long msk = __ballot(a0 < c);                                                                   \
+        asm volatile("v_cmp_lt_f32 vcc, %0, %1" ::"v"(a0), "v"(c) : "vcc");                                           \
+        for (int i = 0; i < N_ITER; i++) {                                                                             \
+            _Pragma("unroll") for (int u = 0; u < 1; u++) { REP8(ASM) }                                                \
+        }                                                                                                              \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + c + d;                   \
+    }
+#define OP_MUL(x) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(c));
+#define OP_SUB(x) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x) : "v"(c));
+#define OP_MIN(x) asm volatile("v_min_f32 %0, %0, %1" : "+v"(x) : "v"(c));
+#define OP_MAX(x) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x) : "v"(c));
+#define OP_MIN3(x) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(d));
+#define OP_MAX3(x) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(d));
+#define OP_MED3(x) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(d));
+#define OP_CND(x) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x) : "v"(c));
+#define OP_CNDS(x) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(c), "s"(msk));
+#define OP_MINU(x) asm volatile("v_min_u32 %0, %0, %1" : "+v"(x) : "v"(c));
+#define OP_MAXI(x) asm volatile("v_max_i32 %0, %0, %1" : "+v"(x) : "v"(c));
+#define OP_MUL64(x) asm volatile("v_mul_f32_e64 %0, %0, %1" : "+v"(x) : "v"(c));
+#define OP_SUBS(x) asm volatile("v_sub_f32_e32 %0, s20, %0" : "+v"(x));
+#define OP_MULNEG(x) asm volatile("v_mul_f32_e64 %0, -%0, %1" : "+v"(x) : "v"(c));
+#define OP_MAXABS(x) asm volatile("v_max_f32_e64 %0, |%0|, %1" : "+v"(x) : "v"(c));
+#define OP_CMP(x) asm volatile("v_cmp_lt_f32 vcc, %0, %1" ::"v"(x), "v"(c) : "vcc");
+#define OP_CMPS(x) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1" ::"v"(x), "v"(c) : "s20", "s21");
+#define OP_FMA(x) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(d));
+#define OP_MULLO(x) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x) : "v"(c));
+#define OP_MUL24(x) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x) : "v"(c));
+#define OP_MAD24(x) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(d));
+#define OP_XOR(x) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(c));
+#define OP_LSHR(x) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(x));
+#define OP_LSHLADD(x) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(x) : "v"(c));
+#define OP_ADDU(x) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(c));
+#define OP_CVT(x) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(x));
+#define OP_RCP(x) asm volatile("v_rcp_f32 %0, %0" : "+v"(x));
+#define OP_RSQ(x) asm volatile("v_rsq_f32 %0, %0" : "+v"(x));
+#define OP_MOV(x) asm volatile("v_mov_b32 %0, %1" : "+v"(x) : "v"(c));
+#define OP_BFE(x) asm volatile("v_bfe_u32 %0, %0, 3, 7" : "+v"(x));
+#define OP_ANDOR(x) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(d));
+K(mul, OP_MUL) K(sub, OP_SUB) K(min, OP_MIN) K(max, OP_MAX) K(min3, OP_MIN3) K(max3, OP_MAX3) K(med3, OP_MED3) K(cnd, OP_CND) K(cmp, OP_CMP) K(cmps, OP_CMPS)
+K(cnds, OP_CNDS) K(minu, OP_MINU) K(maxi, OP_MAXI) K(mul64, OP_MUL64) K(subs, OP_SUBS) K(mulneg, OP_MULNEG) K(maxabs, OP_MAXABS)
+K(fma, OP_FMA) K(mullo, OP_MULLO) K(mul24, OP_MUL24) K(mad24, OP_MAD24) K(xorb, OP_XOR) K(lshr, OP_LSHR) K(lshladd, OP_LSHLADD) K(addu, OP_ADDU)
+K(cvt, OP_CVT) K(rcp, OP_RCP) K(rsq, OP_RSQ) K(mov, OP_MOV) K(bfe, OP_BFE) K(andor, OP_ANDOR)
+template <typename F> void run(const char* name, F kern, float* d)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int blocks = 256 * 8; // 8 waves per SIMD
+    kern<<<blocks, 256>>>(d, 1.0001f); hipDeviceSynchronize();
+    hipEventRecord(e0); kern<<<blocks, 256>>>(d, 1.0001f); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double waveInstr = (double)blocks * 4 * N_ITER * 8;
+    printf("%-14s %7.3f ms  -> %5.2f cycles per wave64 instruction per SIMD (at 2.4 GHz)\n", name, ms, ms * 1e-3 * 2.4e9 * 1024 / waveInstr);
+}
+int main()
+{
+    float* d; hipMalloc(&d, 256 * 8 * 256 * 4);
+#define R(n) run(#n, k_##n, d);
+    R(mul) R(sub) R(fma) R(min) R(max) R(min3) R(max3) R(med3) R(cnd) R(cnds) R(cmp) R(cmps) R(minu) R(maxi) R(mul64) R(subs) R(mulneg) R(maxabs) R(mov) R(xorb) R(lshr) R(lshladd) R(addu) R(bfe) R(andor) R(mullo) R(mul24) R(mad24) R(cvt) R(rcp) R(rsq)
+    return 0;
+}
