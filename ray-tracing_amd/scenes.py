@@ -207,7 +207,28 @@ def glass_balls(numRaysPerPixel=8, width=1920, height=1080):
     return sc
 
 
-CONFIGS = {1: config1, 2: config2, 3: config3, 4: config4, 5: config5, 6: glass_balls}
+def reference_scene(short_name, numRaysPerPixel=None, width=None, height=None):
+    """The reference's other scene files — `Glass Dragon`, `Sphere Refract`, `Splash`, `Text` (.unity) — as transcribed by
+    tools/convert_reference_scenes.py into scenes_data/<short_name>.json: every transform, material, manager and camera
+    setting as serialized upstream (maxBounceCount 32 in three of them, depth of field in `Sphere Refract`, Quality.Low
+    BVHs in `Splash`, 18 models in `Text`); meshes that are engine resources or missing blobs are the declared stand-ins."""
+    import os
+    from . import sceneio
+    sc = sceneio.load_scene(os.path.join(os.path.dirname(os.path.abspath(__file__)), "scenes_data", short_name + ".json"))
+    sc.name = short_name + "_reference_scene"
+    if width and height:
+        sc.width, sc.height = width, height
+    if numRaysPerPixel:
+        sc.settings["numRaysPerPixel"] = numRaysPerPixel
+    return sc
+
+
+def _ref(short_name):
+    return lambda **kw: reference_scene(short_name, **kw)
+
+
+CONFIGS = {1: config1, 2: config2, 3: config3, 4: config4, 5: config5, 6: glass_balls,
+           7: _ref("glass_dragon"), 8: _ref("sphere_refract"), 9: _ref("splash"), 10: _ref("text")}
 
 
 def get(config_id, **kw):

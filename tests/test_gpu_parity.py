@@ -66,6 +66,15 @@ def test_bit_exact_against_oracle(pkg, api, orc, cfg, w, h, frames, kw):
     assert [ca[k] for k in KEYS] == [cb[k] for k in KEYS]
 
 
+@pytest.mark.parametrize("cfg,w,h,frames", [(7, 96, 54, 3), (8, 80, 45, 3), (9, 96, 54, 4), (10, 88, 50, 3)])
+def test_the_references_other_scenes_bit_exact(pkg, api, orc, cfg, w, h, frames):
+    """`Glass Dragon`, `Sphere Refract` (depth of field, 32 bounces), `Splash` (Quality.Low BVHs, 32 bounces) and `Text`
+    (18 models, 32 bounces) as transcribed from the reference's scene files: HIP (shipped and stats kernels) == oracle."""
+    a, b, ca, cb = pair(pkg, api, orc, cfg, w, h, frames)
+    assert bits_equal(a, b)
+    assert [ca[k] for k in KEYS] == [cb[k] for k in KEYS]
+
+
 def test_config4_full_mesh_bit_exact(pkg, api, orc):
     """The real 81,920-triangle mesh (BVH depth ~20), small image."""
     a, b, ca, cb = pair(pkg, api, orc, 4, 96, 54, 1)
