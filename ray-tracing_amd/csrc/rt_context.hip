@@ -444,7 +444,11 @@ int rt_get_render_targets(RtContext* ctx, void** d_frame, void** d_accum)
  * double).  *bound = max_k(|c_k|^2 + r_k^2), rounded up: it scales the pre-test's error margin. */
 static void pack_spheres(const RtSphere* spheres, int n, std::vector<float>& out, float* bound)
 {
-    out.assign((size_t)n * 8, 0.0f);
+    /* n exact records (c, r*r), then ceil(n/2) PAIR records of the conservative pre-test: (cx0, cx1, cy0, cy1, cz0, cz1, K0, K1)
+     * with K = |c|^2 - r*r — two spheres side by side, so that one scalar load fills the SGPR pairs a packed fp32
+     * instruction takes (begin_intersect); an odd last sphere is paired with itself */
+    const size_t pairs = ((size_t)n + 1) / 2;
+    out.assign((size_t)n * 4 + pairs * 8, 0.0f);
     double maxM = 0;
     for (int i = 0; i < n; i++) {
         const float* c = spheres[i].centre;
@@ -452,8 +456,11 @@ static void pack_spheres(const RtSphere* spheres, int n, std::vector<float>& out
         memcpy(&out[4 * (size_t)i], c, 12);
         out[4 * (size_t)i + 3] = r2;
         const double cc = (double)c[0] * c[0] + (double)c[1] * c[1] + (double)c[2] * c[2];
-        memcpy(&out[4 * ((size_t)n + i)], c, 12);
-        out[4 * ((size_t)n + i) + 3] = (float)(cc - (double)r2);
+        const float K = (float)(cc - (double)r2);
+        float* q = &out[4 * (size_t)n + 8 * (size_t)(i / 2)];
+        const int h = i & 1;
+        q[0 + h] = c[0]; q[2 + h] = c[1]; q[4 + h] = c[2]; q[6 + h] = K;
+        if (!h && i == n - 1) { q[1] = c[0]; q[3] = c[1]; q[5] = c[2]; q[7] = K; }
         if (cc + (double)r2 > maxM) maxM = cc + (double)r2;
     }
     *bound = (float)(maxM * 1.000001);
@@ -1647,6 +1654,12 @@ int rt_debug_phase_profile(RtContext* ctx, uint64_t* out, int n)
     if (n > 2 * RT_N_PHASES) { /* audit of the conservative root filter: must be 0 */
         out[2 * RT_N_PHASES] = 0;
         for (int s = 0; s < RT_COUNTER_SLOTS; s++) out[2 * RT_N_PHASES] += h[(size_t)s * RT_COUNTER_FIELDS + 6];
+    }
+    for (int p = 0; p < RT_N_PHASES && 2 * RT_N_PHASES + 1 + p < n; p++) { /* elapsed ticks per coarse phase: measurement build only, else 0 */
+        out[2 * RT_N_PHASES + 1 + p] = 0;
+#ifdef RT_PHASE_TIMES
+        for (int s = 0; s < RT_COUNTER_SLOTS; s++) out[2 * RT_N_PHASES + 1 + p] += h[(size_t)s * RT_COUNTER_FIELDS + 8 + 2 * RT_N_PHASES + p];
+#endif
     }
     return RT_OK;
 }

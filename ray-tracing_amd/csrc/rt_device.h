@@ -37,7 +37,11 @@
 #else
 #define RT_COLD_STRIDE_BYTES (2 * RT_WAVE * 16)
 #endif
+#ifdef RT_PHASE_TIMES /* measurement build (make phase-times): + elapsed shader-clock ticks per coarse phase */
+#define RT_COUNTER_FIELDS (8 + 3 * RT_N_PHASES)
+#else
 #define RT_COUNTER_FIELDS (8 + 2 * RT_N_PHASES)
+#endif
 
 /* node codes: bit31 = leaf.  leaf: [30:24] = triangle count (1..127), [23:0] = first
  * triangle (relative to the model's triOffset); count field 0 = indirect, [23:0]
@@ -103,7 +107,7 @@ struct DMaterial {
 struct KArgs {
     /* scene */
     const float* spheres;        /* nSpheres x (cx, cy, cz, r*r) */
-    const float* sphereQuick;    /* nSpheres x (cx, cy, cz, |c|^2 - r*r): conservative pre-test */
+    const float* sphereQuick;    /* ceil(nSpheres / 2) x (cx0, cx1, cy0, cy1, cz0, cz1, K0, K1), K = |c|^2 - r*r: the conservative pre-test, two spheres per record */
     float sphereBound;           /* max_k(|c_k|^2 + r_k^2): scales the pre-test's error margin */
     const DMaterial* materials;  /* [0,nSpheres) spheres, then models */
     const DModel* models;

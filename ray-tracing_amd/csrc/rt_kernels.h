@@ -97,6 +97,14 @@ struct Stats {
     /* wave-level phase profile (stats launches only): how often the wave executed a phase
      * and how many lanes were active in it — lane utilisation per phase = lanes / (64 * execs) */
     uint32_t phExec[RT_N_PHASES], phLanes[RT_N_PHASES];
+#ifdef RT_PHASE_TIMES
+    /* measurement build only: elapsed time (s_memtime ticks) between the marks of the COARSE phases — loop top, refill, camera
+     * ray, spheres + filter, the whole traverse() call, sky, shade, glass; what follows a mark up to the next one is charged
+     * to it (frame end -> loop, roulette / path end -> the shading phase before it) */
+    uint64_t phT[RT_N_PHASES];
+    uint64_t tPrev;
+    int phPrev;
+#endif
 };
 enum { PH_LOOP = 0, PH_RAYGEN, PH_SPHERES, PH_TRAVERSE_CALL, PH_MODEL, PH_INNER, PH_TRI, PH_SHADE_HIT, PH_SKY, PH_SPHERE_ROOTS, PH_GLASS, PH_REFILL };
 template <bool STATS>
@@ -106,6 +114,17 @@ __device__ __forceinline__ void phase_mark(Stats& st, int ph)
         const unsigned long long m = __ballot(1);
         st.phLanes[ph]++;
         if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) st.phExec[ph]++;
+#ifdef RT_PHASE_TIMES
+        if (ph != PH_MODEL && ph != PH_INNER && ph != PH_TRI && ph != PH_SPHERE_ROOTS) {
+            __builtin_amdgcn_sched_barrier(0); /* the timestamp stays where the mark is: nothing is scheduled across it */
+            const uint64_t now = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): the time is the time of the mark, not of its first use */
+            __builtin_amdgcn_sched_barrier(0);
+            if (st.phPrev >= 0) st.phT[st.phPrev] += now - st.tPrev;
+            st.tPrev = now;
+            st.phPrev = ph;
+        }
+#endif
     }
 }
 
@@ -279,26 +298,38 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
     const float od = __builtin_fmaf(rpos.x, rdir.x, __builtin_fmaf(rpos.y, rdir.y, rpos.z * rdir.z));
     const float oo = __builtin_fmaf(rpos.x, rpos.x, __builtin_fmaf(rpos.y, rpos.y, rpos.z * rpos.z));
     const float negMargin = -(7.62939453125e-06f * qa * (oo + a.sphereBound)); /* 2^-17 */
+    /* Two spheres per step, side by side in packed fp32 instructions: the sphere data sits in SGPRs, and on gfx950 a VALU
+     * instruction with an SGPR source issues at the slow rate (4.5 cycles against 2.9, profiles/r03_valu_op_rates.txt) while
+     * v_pk_fma/mul/add_f32 take an SGPR pair at no extra cost (5.0 cycles for both halves) — the same operations on the same
+     * values per sphere, so the candidate masks do not change. */
+    typedef float rt_f2v __attribute__((ext_vector_type(2)));
+    const rt_f2v dx2 = {rdir.x, rdir.x}, dy2 = {rdir.y, rdir.y}, dz2 = {rdir.z, rdir.z};
+    const rt_f2v ox2 = {rpos.x, rpos.x}, oy2 = {rpos.y, rpos.y}, oz2 = {rpos.z, rpos.z};
+    const rt_f2v od2 = {od, od}, oo2 = {oo, oo}, qa2 = {qa, qa}, m2 = {-2.0f, -2.0f};
     for (int base = 0; base < a.nSpheres; base += 32) {
         const int n = (a.nSpheres - base) < 32 ? (a.nSpheres - base) : 32;
         uint32_t cand = 0;
-        for (int k = 0; k < n; k++) {
-            const int s = base + k;
-            const float cx = sphq[4 * s + 0], cy = sphq[4 * s + 1], cz = sphq[4 * s + 2];
-            const float cd = __builtin_fmaf(cx, rdir.x, __builtin_fmaf(cy, rdir.y, cz * rdir.z));
-            const float co = __builtin_fmaf(cx, rpos.x, __builtin_fmaf(cy, rpos.y, cz * rpos.z));
-            const float b = od - cd;
-            const float ct = __builtin_fmaf(-2.0f, co, oo) + sphq[4 * s + 3];
-            const float dq = __builtin_fmaf(b, b, -(qa * ct));
-            const bool keep = !(dq < negMargin);
+        for (int k = 0; k < n; k += 2) {
+            const RT_CAS float* q = sphq + 4 * (base + k); /* pair record (base + k) / 2, eight floats each */
+            const rt_f2v cx = {q[0], q[1]}, cy = {q[2], q[3]}, cz = {q[4], q[5]}, kk = {q[6], q[7]};
+            const rt_f2v cd = __builtin_elementwise_fma(cx, dx2, __builtin_elementwise_fma(cy, dy2, cz * dz2));
+            const rt_f2v co = __builtin_elementwise_fma(cx, ox2, __builtin_elementwise_fma(cy, oy2, cz * oz2));
+            const rt_f2v b = od2 - cd;
+            const rt_f2v ct = __builtin_elementwise_fma(m2, co, oo2) + kk;
+            const rt_f2v dq = __builtin_elementwise_fma(b, b, -(qa2 * ct));
+            const bool keep0 = !(dq.x < negMargin);
+            const bool keep1 = (k + 1 < n) && !(dq.y < negMargin);
             if (STATS) { /* audit against the reference's discriminant */
-                rt_f3 off = rpos - rt_v3(sph[4 * s + 0], sph[4 * s + 1], sph[4 * s + 2]);
-                float qb = 2 * rt_dot(off, rdir);
-                float qc = rt_dot(off, off) - sph[4 * s + 3];
-                float disc = qb * qb - 4 * qa * qc;
-                if (disc >= 0 && !keep) st.filterViolations++;
+                for (int j = 0; j < 2 && k + j < n; j++) {
+                    const int s = base + k + j;
+                    rt_f3 off = rpos - rt_v3(sph[4 * s + 0], sph[4 * s + 1], sph[4 * s + 2]);
+                    float qb = 2 * rt_dot(off, rdir);
+                    float qc = rt_dot(off, off) - sph[4 * s + 3];
+                    float disc = qb * qb - 4 * qa * qc;
+                    if (disc >= 0 && !(j ? keep1 : keep0)) st.filterViolations++;
+                }
             }
-            cand |= (keep ? 1u : 0u) << k;
+            cand |= ((keep0 ? 1u : 0u) << k) | ((keep1 ? 1u : 0u) << (k + 1));
         }
         while (cand) {
             phase_mark<STATS>(st, PH_SPHERE_ROOTS);
@@ -815,6 +846,9 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
     t.cand = 0; t.rootStep = false; t.m = 0; t.cur = RT_CODE_NEXT_MODEL; t.sp = 0; t.lpos = t.ldir = t.linv = rt_v3s(0.0f); t.triBase = 0; t.cull = true;
     uint32_t segments = 0;
     Stats st = {};
+#ifdef RT_PHASE_TIMES
+    st.phPrev = -1;
+#endif
 
     for (;;) {
         /* ---- hand pixels to idle lanes (every lane of the wave is active here) */
@@ -1098,6 +1132,9 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
             if (lane == 0) {
                 atomicAdd(slot + 8 + 2 * p, (unsigned long long)e);
                 atomicAdd(slot + 9 + 2 * p, (unsigned long long)l);
+#ifdef RT_PHASE_TIMES
+                atomicAdd(slot + 8 + 2 * RT_N_PHASES + p, (unsigned long long)st.phT[p]); /* wave-uniform: lane 0's copy */
+#endif
             }
         }
     } else if (lane == 0) {

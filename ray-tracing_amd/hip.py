@@ -273,10 +273,13 @@ class HipTracer(abi.Tracer):
     PHASES = ["loop", "raygen", "spheres", "traverse_call", "model", "inner", "tri", "shade_hit", "sky", "sphere_roots", "glass", "refill"]
 
     def phase_profile(self):
-        out = np.zeros(2 * len(self.PHASES) + 1, dtype=np.uint64)
+        n = len(self.PHASES)
+        out = np.zeros(3 * n + 1, dtype=np.uint64)
         self._check(self.api.debug_phase_profile(self.h, out.ctypes.data, len(out)))
         prof = {p: (int(out[2 * i]), int(out[2 * i + 1])) for i, p in enumerate(self.PHASES)}
-        prof["filter_violations"] = (int(out[-1]), 0)
+        prof["filter_violations"] = (int(out[2 * n]), 0)
+        if out[2 * n + 1:].any():   # a `make phase-times` build: elapsed shader-clock ticks per coarse phase, summed over waves
+            prof["elapsed_ticks"] = {p: int(out[2 * n + 1 + i]) for i, p in enumerate(self.PHASES) if out[2 * n + 1 + i]}
         return prof
 
     def debug_math_eval(self, op, x, y=None):

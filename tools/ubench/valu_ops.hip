@@ -9,12 +9,15 @@
     {                                                                                                                  \
         float a0 = seed + threadIdx.x, a1 = a0 * 1.1f, a2 = a0 * 1.2f, a3 = a0 * 1.3f, a4 = a0 * 1.4f, a5 = a0 * 1.5f, a6 = a0 * 1.6f, a7 = a0 * 1.7f; \
         float c = seed * 0.999f, d = seed * 1.001f;                                                                    \
+        typedef float f2 __attribute__((ext_vector_type(2)));                                                          \
+        f2 pa0 = {a0, a1}, pa1 = {a2, a3}, pa2 = {a4, a5}, pa3 = {a6, a7}, pa4 = {a1, a0}, pa5 = {a3, a2}, pa6 = {a5, a4}, pa7 = {a7, a6}, pc = {c, d}; \
+        asm volatile("s_mov_b32 s20, 0x3f7fbe77\n s_mov_b32 s21, 0x3f800347" ::: "s20", "s21");                                                                    \
         unsigned long long msk = __ballot(a0 < c);                                                                   \
         asm volatile("v_cmp_lt_f32 vcc, %0, %1" ::"v"(a0), "v"(c) : "vcc");                                           \
         for (int i = 0; i < N_ITER; i++) {                                                                             \
             _Pragma("unroll") for (int u = 0; u < 1; u++) { REP8(ASM) }                                                \
         }                                                                                                              \
-        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + c + d;                   \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + c + d + pa0.x + pa1.y + pa2.x + pa3.y + pa4.x + pa5.y + pa6.x + pa7.y;                   \
     }
 #define OP_MUL(x) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(c));
 #define OP_SUB(x) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x) : "v"(c));
@@ -44,11 +47,19 @@
 #define OP_CVT(x) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(x));
 #define OP_RCP(x) asm volatile("v_rcp_f32 %0, %0" : "+v"(x));
 #define OP_RSQ(x) asm volatile("v_rsq_f32 %0, %0" : "+v"(x));
+#define OP_PKMUL(x) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p##x) : "v"(pc));
+#define OP_PKMULS(x) asm volatile("v_pk_mul_f32 %0, %0, s[20:21]" : "+v"(p##x));
+#define OP_PKFMA(x) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p##x) : "v"(pc));
+#define OP_PKFMAS(x) asm volatile("v_pk_fma_f32 %0, %0, s[20:21], %1" : "+v"(p##x) : "v"(pc));
+#define OP_PKADD(x) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p##x) : "v"(pc));
+#define OP_FMAS(x) asm volatile("v_fma_f32 %0, %0, s20, %1" : "+v"(x) : "v"(c));
+#define OP_MULS(x) asm volatile("v_mul_f32_e32 %0, s20, %0" : "+v"(x));
 #define OP_MOV(x) asm volatile("v_mov_b32 %0, %1" : "+v"(x) : "v"(c));
 #define OP_BFE(x) asm volatile("v_bfe_u32 %0, %0, 3, 7" : "+v"(x));
 #define OP_ANDOR(x) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(d));
 K(mul, OP_MUL) K(sub, OP_SUB) K(min, OP_MIN) K(max, OP_MAX) K(min3, OP_MIN3) K(max3, OP_MAX3) K(med3, OP_MED3) K(cnd, OP_CND) K(cmp, OP_CMP) K(cmps, OP_CMPS)
 K(cnds, OP_CNDS) K(minu, OP_MINU) K(maxi, OP_MAXI) K(mul64, OP_MUL64) K(subs, OP_SUBS) K(mulneg, OP_MULNEG) K(maxabs, OP_MAXABS)
+K(pkmul, OP_PKMUL) K(pkmuls, OP_PKMULS) K(pkfma, OP_PKFMA) K(pkfmas, OP_PKFMAS) K(pkadd, OP_PKADD) K(fmas, OP_FMAS) K(muls, OP_MULS)
 K(fma, OP_FMA) K(mullo, OP_MULLO) K(mul24, OP_MUL24) K(mad24, OP_MAD24) K(xorb, OP_XOR) K(lshr, OP_LSHR) K(lshladd, OP_LSHLADD) K(addu, OP_ADDU)
 K(cvt, OP_CVT) K(rcp, OP_RCP) K(rsq, OP_RSQ) K(mov, OP_MOV) K(bfe, OP_BFE) K(andor, OP_ANDOR)
 template <typename F> void run(const char* name, F kern, float* d)
@@ -65,6 +76,6 @@ int main()
 {
     float* d; hipMalloc(&d, 256 * 8 * 256 * 4);
 #define R(n) run(#n, k_##n, d);
-    R(mul) R(sub) R(fma) R(min) R(max) R(min3) R(max3) R(med3) R(cnd) R(cnds) R(cmp) R(cmps) R(minu) R(maxi) R(mul64) R(subs) R(mulneg) R(maxabs) R(mov) R(xorb) R(lshr) R(lshladd) R(addu) R(bfe) R(andor) R(mullo) R(mul24) R(mad24) R(cvt) R(rcp) R(rsq)
+    R(mul) R(muls) R(sub) R(fma) R(fmas) R(pkmul) R(pkmuls) R(pkadd) R(pkfma) R(pkfmas) R(min) R(max) R(min3) R(max3) R(med3) R(cnd) R(cnds) R(cmp) R(cmps) R(minu) R(maxi) R(mul64) R(subs) R(mulneg) R(maxabs) R(mov) R(xorb) R(lshr) R(lshladd) R(addu) R(bfe) R(andor) R(mullo) R(mul24) R(mad24) R(cvt) R(rcp) R(rsq)
     return 0;
 }
