@@ -54,12 +54,19 @@
 #define OP_PKADD(x) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p##x) : "v"(pc));
 #define OP_FMAS(x) asm volatile("v_fma_f32 %0, %0, s20, %1" : "+v"(x) : "v"(c));
 #define OP_MULS(x) asm volatile("v_mul_f32_e32 %0, s20, %0" : "+v"(x));
+#define OP_MULLIT(x) asm volatile("v_mul_f32_e32 %0, 0x3f317218, %0" : "+v"(x));
+#define OP_ADDLIT(x) asm volatile("v_add_f32_e32 %0, 0x3f317218, %0" : "+v"(x));
+#define OP_FMALIT(x) asm volatile("v_fmac_f32_e32 %0, 0x3f317218, %1" : "+v"(x) : "v"(c));
+#define OP_FMAK(x) asm volatile("v_fmaak_f32 %0, %0, %1, 0x3f317218" : "+v"(x) : "v"(c));
+#define OP_MULINL(x) asm volatile("v_mul_f32_e32 %0, 0.5, %0" : "+v"(x));
+#define OP_FMAC(x) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(x) : "v"(c), "v"(d));
 #define OP_MOV(x) asm volatile("v_mov_b32 %0, %1" : "+v"(x) : "v"(c));
 #define OP_BFE(x) asm volatile("v_bfe_u32 %0, %0, 3, 7" : "+v"(x));
 #define OP_ANDOR(x) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(d));
 K(mul, OP_MUL) K(sub, OP_SUB) K(min, OP_MIN) K(max, OP_MAX) K(min3, OP_MIN3) K(max3, OP_MAX3) K(med3, OP_MED3) K(cnd, OP_CND) K(cmp, OP_CMP) K(cmps, OP_CMPS)
 K(cnds, OP_CNDS) K(minu, OP_MINU) K(maxi, OP_MAXI) K(mul64, OP_MUL64) K(subs, OP_SUBS) K(mulneg, OP_MULNEG) K(maxabs, OP_MAXABS)
 K(pkmul, OP_PKMUL) K(pkmuls, OP_PKMULS) K(pkfma, OP_PKFMA) K(pkfmas, OP_PKFMAS) K(pkadd, OP_PKADD) K(fmas, OP_FMAS) K(muls, OP_MULS)
+K(mullit, OP_MULLIT) K(addlit, OP_ADDLIT) K(fmalit, OP_FMALIT) K(fmak, OP_FMAK) K(mulinl, OP_MULINL) K(fmac, OP_FMAC)
 K(fma, OP_FMA) K(mullo, OP_MULLO) K(mul24, OP_MUL24) K(mad24, OP_MAD24) K(xorb, OP_XOR) K(lshr, OP_LSHR) K(lshladd, OP_LSHLADD) K(addu, OP_ADDU)
 K(cvt, OP_CVT) K(rcp, OP_RCP) K(rsq, OP_RSQ) K(mov, OP_MOV) K(bfe, OP_BFE) K(andor, OP_ANDOR)
 template <typename F> void run(const char* name, F kern, float* d)
@@ -76,6 +83,6 @@ int main()
 {
     float* d; hipMalloc(&d, 256 * 8 * 256 * 4);
 #define R(n) run(#n, k_##n, d);
-    R(mul) R(muls) R(sub) R(fma) R(fmas) R(pkmul) R(pkmuls) R(pkadd) R(pkfma) R(pkfmas) R(min) R(max) R(min3) R(max3) R(med3) R(cnd) R(cnds) R(cmp) R(cmps) R(minu) R(maxi) R(mul64) R(subs) R(mulneg) R(maxabs) R(mov) R(xorb) R(lshr) R(lshladd) R(addu) R(bfe) R(andor) R(mullo) R(mul24) R(mad24) R(cvt) R(rcp) R(rsq)
+    R(mul) R(mullit) R(addlit) R(fmalit) R(fmak) R(mulinl) R(fmac) R(muls) R(sub) R(fma) R(fmas) R(pkmul) R(pkmuls) R(pkadd) R(pkfma) R(pkfmas) R(min) R(max) R(min3) R(max3) R(med3) R(cnd) R(cnds) R(cmp) R(cmps) R(minu) R(maxi) R(mul64) R(subs) R(mulneg) R(maxabs) R(mov) R(xorb) R(lshr) R(lshladd) R(addu) R(bfe) R(andor) R(mullo) R(mul24) R(mad24) R(cvt) R(rcp) R(rsq)
     return 0;
 }
