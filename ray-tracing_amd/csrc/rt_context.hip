@@ -892,6 +892,10 @@ static int prepare_scene(RtContext* ctx, const RtModel* models, int n_models, co
         }
     }
 
+    /* the kernels address pairs and triangles with 32-bit byte offsets from the array bases (rt_kernels.h) */
+    if (sb.pairs.size() >= ((size_t)1 << 26) || (size_t)n_triangles * sizeof(DTri) >= ((size_t)1 << 32))
+        return fail(ctx, RT_ERR_SCENE, "scene too large for 32-bit offsets: %zu node pairs (limit 2^26), %d triangles (limit 2^32 / 48)", sb.pairs.size(), n_triangles);
+
     /* ---- triangles: RC:190-192 are ray independent, pre-difference them (same fp32 ops) */
     std::vector<DTri>& dtris = ps.dtris;
     std::vector<DTriN>& dnorms = ps.dnorms;

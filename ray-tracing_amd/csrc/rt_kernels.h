@@ -224,7 +224,9 @@ __device__ __forceinline__ rt_f3 material_colour(const DMaterial& mat, rt_f3 pos
 __device__ __forceinline__ void tri_test(const DTri* __restrict__ tris, int triIndex, rt_f3 pos, rt_f3 dir, bool cull,
                                          float& bestDst, int& bestTri, float& bu, float& bv, float& bdet)
 {
-    const float4* p = reinterpret_cast<const float4*>(tris + triIndex);
+    /* 32-bit byte offset from the uniform array base (SGPR base + VGPR offset addressing, see the inner step);
+     * rt_upload_scene refuses scenes whose triangle array reaches 4 GiB */
+    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tris) + (uint32_t)triIndex * 48u);
     float4 q0 = p[0], q1 = p[1], q2 = p[2];
     rt_f3 A = rt_v3(q0.x, q0.y, q0.z);
     rt_f3 edgeAB = rt_v3(q0.w, q1.x, q1.y);
@@ -570,7 +572,10 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
                 t.rootStep = false;
                 phase_mark<STATS>(st, PH_INNER);
 #ifndef RT_LDS_NODE_FETCH
-                const float4* q = reinterpret_cast<const float4*>(pairs + t.cur);
+                /* a 32-bit byte offset from the (wave-uniform) array base: the load takes "SGPR base + VGPR offset" and the
+                 * 64-bit shift and add of a full pointer (two slow-class VALU instructions per step on gfx950) become one fast
+                 * 32-bit shift; rt_upload_scene refuses scenes with 2^26 pairs or more */
+                const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pairs) + (uint32_t)(t.cur << 6));
                 const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
 #else
                 /* EXPERIMENT kept reproducible (make lds-fetch; profiles/r02_lds_node_fetch.txt): the north_star's

@@ -11,13 +11,14 @@
         float c = seed * 0.999f, d = seed * 1.001f;                                                                    \
         typedef float f2 __attribute__((ext_vector_type(2)));                                                          \
         f2 pa0 = {a0, a1}, pa1 = {a2, a3}, pa2 = {a4, a5}, pa3 = {a6, a7}, pa4 = {a1, a0}, pa5 = {a3, a2}, pa6 = {a5, a4}, pa7 = {a7, a6}, pc = {c, d}; \
+        unsigned long long qa0 = threadIdx.x, qa1 = qa0 + 1, qa2 = qa0 + 2, qa3 = qa0 + 3, qa4 = qa0 + 4, qa5 = qa0 + 5, qa6 = qa0 + 6, qa7 = qa0 + 7, qc = blockIdx.x; \
         asm volatile("s_mov_b32 s20, 0x3f7fbe77\n s_mov_b32 s21, 0x3f800347" ::: "s20", "s21");                                                                    \
         unsigned long long msk = __ballot(a0 < c);                                                                   \
         asm volatile("v_cmp_lt_f32 vcc, %0, %1" ::"v"(a0), "v"(c) : "vcc");                                           \
         for (int i = 0; i < N_ITER; i++) {                                                                             \
             _Pragma("unroll") for (int u = 0; u < 1; u++) { REP8(ASM) }                                                \
         }                                                                                                              \
-        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + c + d + pa0.x + pa1.y + pa2.x + pa3.y + pa4.x + pa5.y + pa6.x + pa7.y;                   \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + c + d + pa0.x + pa1.y + pa2.x + pa3.y + pa4.x + pa5.y + pa6.x + pa7.y + (float)(qa0 + qa1 + qa2 + qa3 + qa4 + qa5 + qa6 + qa7);                   \
     }
 #define OP_MUL(x) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(c));
 #define OP_SUB(x) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x) : "v"(c));
@@ -60,6 +61,9 @@
 #define OP_FMAK(x) asm volatile("v_fmaak_f32 %0, %0, %1, 0x3f317218" : "+v"(x) : "v"(c));
 #define OP_MULINL(x) asm volatile("v_mul_f32_e32 %0, 0.5, %0" : "+v"(x));
 #define OP_FMAC(x) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(x) : "v"(c), "v"(d));
+#define OP_MAD64(x) asm volatile("v_mad_i64_i32 %0, vcc, %1, 48, %0" : "+v"(q##x) : "v"(x) : "vcc");
+#define OP_LSHLADD64(x) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q##x) : "v"(qc));
+#define OP_LSHL64(x) asm volatile("v_lshlrev_b64 %0, 6, %0" : "+v"(q##x));
 #define OP_MOV(x) asm volatile("v_mov_b32 %0, %1" : "+v"(x) : "v"(c));
 #define OP_BFE(x) asm volatile("v_bfe_u32 %0, %0, 3, 7" : "+v"(x));
 #define OP_ANDOR(x) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(d));
@@ -67,6 +71,7 @@ K(mul, OP_MUL) K(sub, OP_SUB) K(min, OP_MIN) K(max, OP_MAX) K(min3, OP_MIN3) K(m
 K(cnds, OP_CNDS) K(minu, OP_MINU) K(maxi, OP_MAXI) K(mul64, OP_MUL64) K(subs, OP_SUBS) K(mulneg, OP_MULNEG) K(maxabs, OP_MAXABS)
 K(pkmul, OP_PKMUL) K(pkmuls, OP_PKMULS) K(pkfma, OP_PKFMA) K(pkfmas, OP_PKFMAS) K(pkadd, OP_PKADD) K(fmas, OP_FMAS) K(muls, OP_MULS)
 K(mullit, OP_MULLIT) K(addlit, OP_ADDLIT) K(fmalit, OP_FMALIT) K(fmak, OP_FMAK) K(mulinl, OP_MULINL) K(fmac, OP_FMAC)
+K(mad64, OP_MAD64) K(lshladd64, OP_LSHLADD64) K(lshl64, OP_LSHL64)
 K(fma, OP_FMA) K(mullo, OP_MULLO) K(mul24, OP_MUL24) K(mad24, OP_MAD24) K(xorb, OP_XOR) K(lshr, OP_LSHR) K(lshladd, OP_LSHLADD) K(addu, OP_ADDU)
 K(cvt, OP_CVT) K(rcp, OP_RCP) K(rsq, OP_RSQ) K(mov, OP_MOV) K(bfe, OP_BFE) K(andor, OP_ANDOR)
 template <typename F> void run(const char* name, F kern, float* d)
@@ -83,6 +88,6 @@ int main()
 {
     float* d; hipMalloc(&d, 256 * 8 * 256 * 4);
 #define R(n) run(#n, k_##n, d);
-    R(mul) R(mullit) R(addlit) R(fmalit) R(fmak) R(mulinl) R(fmac) R(muls) R(sub) R(fma) R(fmas) R(pkmul) R(pkmuls) R(pkadd) R(pkfma) R(pkfmas) R(min) R(max) R(min3) R(max3) R(med3) R(cnd) R(cnds) R(cmp) R(cmps) R(minu) R(maxi) R(mul64) R(subs) R(mulneg) R(maxabs) R(mov) R(xorb) R(lshr) R(lshladd) R(addu) R(bfe) R(andor) R(mullo) R(mul24) R(mad24) R(cvt) R(rcp) R(rsq)
+    R(mad64) R(lshladd64) R(lshl64) R(mul) R(mullit) R(addlit) R(fmalit) R(fmak) R(mulinl) R(fmac) R(muls) R(sub) R(fma) R(fmas) R(pkmul) R(pkmuls) R(pkadd) R(pkfma) R(pkfmas) R(min) R(max) R(min3) R(max3) R(med3) R(cnd) R(cnds) R(cmp) R(cmps) R(minu) R(maxi) R(mul64) R(subs) R(mulneg) R(maxabs) R(mov) R(xorb) R(lshr) R(lshladd) R(addu) R(bfe) R(andor) R(mullo) R(mul24) R(mad24) R(cvt) R(rcp) R(rsq)
     return 0;
 }
