@@ -20,7 +20,11 @@
 
 #include <chrono>
 
+#ifdef RT_QUEUED_EXPERIMENT /* make queued: the queued-stages form of the trace kernel, measured 3x slower */
+#include "rt_kernels_q.h"
+#else
 #include "rt_kernels.h"
+#endif
 
 #ifndef RT_MAX_FUSED_FRAMES
 #define RT_MAX_FUSED_FRAMES 16
@@ -93,13 +97,18 @@ struct RtContext {
     long long nextSortAt = 1;
     bool lptEnabled = true;
     int numCUs = 256;
-    int occPerCU[6] = {0, 0, 0, 0, 0, 0};
-    size_t occBytes[6] = {0, 0, 0, 0, 0, 0};
+    int occPerCU[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t occBytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool verbose = false;
     /* rt_render_frame calls that arrive while earlier frames are still executing are held back (at most
      * RT_MAX_FUSED_FRAMES) and leave as ONE fused launch at the next call that needs them (flush_pending) */
     void* dPxCold = nullptr; /* pixel records of the resident waves: 2 launch slots (main / side stream) x pxColdWaves x 2 KB */
     long long pxColdWaves = 0;
+    /* queued-stages kernel form (rt_kernels_q.h): BVH scenes with up to 64 models */
+    bool queued = false;        /* RT_QUEUED=1 */
+    int qFlushMin = 16, qRefillMin = 16, qStarveMin = 32; /* RT_Q_FLUSH / RT_Q_REFILL / RT_Q_STARVE (scheduling only) */
+    void* dQRecords = nullptr;  /* 2 launch slots x qWaves x RT_Q_WAVE_DWORDS dwords */
+    long long qWaves = 0;
     int frameGroupOverride = 0; /* RT_FRAME_GROUP: frames per (tile, frame group) item of fused launches (tuning hook) */
     bool coalesce = true;  /* RT_COALESCE=0: every rt_render_frame launches at once */
     int pending = 0;       /* frames [frame - pending, frame) requested but not launched yet */
@@ -294,6 +303,10 @@ int rt_create(int device_id, RtContext** out)
     if (const char* t = getenv("RT_TWO_STREAMS")) ctx->twoStreams = atoi(t) != 0;
     if (const char* c = getenv("RT_COALESCE")) ctx->coalesce = atoi(c) != 0;
     if (const char* fg = getenv("RT_FRAME_GROUP")) ctx->frameGroupOverride = atoi(fg);
+    if (const char* q = getenv("RT_QUEUED")) ctx->queued = atoi(q) != 0;
+    if (const char* q = getenv("RT_Q_FLUSH")) ctx->qFlushMin = atoi(q);
+    if (const char* q = getenv("RT_Q_REFILL")) ctx->qRefillMin = atoi(q);
+    if (const char* q = getenv("RT_Q_STARVE")) ctx->qStarveMin = atoi(q);
     *out = ctx;
     return RT_OK;
 }
@@ -330,6 +343,7 @@ void rt_destroy(RtContext* ctx)
     hipFree(ctx->dDisplay);
     hipFree(ctx->dStaging);
     hipFree(ctx->dPxCold);
+    hipFree(ctx->dQRecords);
     for (auto& pr : ctx->tuner.probe) {
         if (pr.start) hipEventDestroy(pr.start);
         if (pr.stop) hipEventDestroy(pr.stop);
@@ -1197,7 +1211,20 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
     void (*kernHalf)(const KArgs) = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_half_kernel<true, true> : rtk::rt_trace_half_kernel<false, true>)
                                     : many         ? (ctx->stats ? rtk::rt_trace_half_kernel<true, false, true> : rtk::rt_trace_half_kernel<false, false, true>)
                                                    : (ctx->stats ? rtk::rt_trace_half_kernel<true, false> : rtk::rt_trace_half_kernel<false, false>);
-    const int variant = (ctx->flatScene ? 2 : many ? 4 : 0) + (ctx->stats ? 1 : 0);
+    /* EXPERIMENT (make queued): the queued-stages form of the same kernel (rt_kernels_q.h) for BVH scenes with up to 64 models */
+#ifdef RT_QUEUED_EXPERIMENT
+    const bool queued = ctx->queued && !ctx->flatScene && !many;
+    if (queued) {
+        kern = ctx->stats ? rtk::rt_trace_q_kernel<true> : rtk::rt_trace_q_kernel<false>;
+        kernHalf = ctx->stats ? rtk::rt_trace_q_half_kernel<true> : rtk::rt_trace_q_half_kernel<false>;
+        a.qFlushMin = ctx->qFlushMin < 1 ? 1 : ctx->qFlushMin > 64 ? 64 : ctx->qFlushMin;
+        a.qRefillMin = ctx->qRefillMin < 1 ? 1 : ctx->qRefillMin > 64 ? 64 : ctx->qRefillMin;
+        a.qStarveMin = ctx->qStarveMin < 0 ? 0 : ctx->qStarveMin;
+    }
+#else
+    const bool queued = false;
+#endif
+    const int variant = queued ? 6 + (ctx->stats ? 1 : 0) : (ctx->flatScene ? 2 : many ? 4 : 0) + (ctx->stats ? 1 : 0);
     if (ctx->occBytes[variant] != stackBytes + 1) { /* occupancy query cached per (variant, LDS bytes) */
         int perCU = 0;
         HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, RT_WAVE, stackBytes));
@@ -1215,6 +1242,14 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
             HIP_TRY(ctx, hipMalloc(&ctx->dPxCold, (size_t)2 * waves * RT_COLD_STRIDE_BYTES));
             ctx->pxColdWaves = waves;
         }
+#ifdef RT_QUEUED_EXPERIMENT
+        if (queued && ctx->qWaves < waves) {
+            HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
+            hipFree(ctx->dQRecords); ctx->dQRecords = nullptr; ctx->qWaves = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dQRecords, (size_t)2 * waves * RT_Q_WAVE_DWORDS * sizeof(uint32_t)));
+            ctx->qWaves = waves;
+        }
+#endif
     }
     /* longest-chain-first queue order, learnt from the frames already rendered at this size */
     if (ctx->lptEnabled && ctx->orderTiles != tiles) {
@@ -1345,6 +1380,9 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         int grid = (int)(resident < items ? resident : items);
         if (ctx->gridOverride > 0) grid = (int)(ctx->gridOverride < items ? ctx->gridOverride : items);
         a.pxCold = (float4*)((char*)ctx->dPxCold + (size_t)p * ctx->pxColdWaves * RT_COLD_STRIDE_BYTES);
+#ifdef RT_QUEUED_EXPERIMENT
+        a.qRecords = queued ? (uint32_t*)ctx->dQRecords + (size_t)p * ctx->qWaves * RT_Q_WAVE_DWORDS : nullptr;
+#endif
         a.launchTiles = partTiles;
         a.launchItems = (int)items;
         a.orderOffset = p;

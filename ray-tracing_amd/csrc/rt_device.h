@@ -155,6 +155,10 @@ struct KArgs {
     int32_t launchTiles, orderOffset, orderStride;
     int32_t launchItems;         /* queue positions of this launch: launchTiles, or launchTiles * frameGroups (tile, frame group) items */
     float4* pxCold;              /* per-wave pixel records of this launch: [grid][64 lanes][2] float4 (rt_kernels.h, PX_COLD) */
+    uint32_t* qRecords;          /* queued-stages kernel (rt_kernels_q.h): per-wave chain records + parked traversal state, [grid][RT_Q_WAVE_DWORDS] */
+    int32_t qFlushMin;           /* traversal lanes hand their results over when this many have finished */
+    int32_t qRefillMin;          /* free traversal lanes are refilled from rayQ when this many are free */
+    int32_t qStarveMin;          /* fewer rays than this in and before the traversal lanes: partial batches run */
     int32_t frameGroup;          /* consecutive frames per item (>= 1) */
     int32_t frameGroups;         /* ceil(nFrames / frameGroup) */
     float* staging;              /* nFrames > 1: [frame - frame0][stagingStride pixels] RGBA colours awaiting rt_accumulate_kernel */

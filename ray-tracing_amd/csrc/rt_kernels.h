@@ -487,7 +487,8 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
  * single, wave-uniform exit (finished lanes park in RT_CODE_DONE instead of leaving one by
  * one), which keeps the loop-carried state in one set of registers. */
 template <bool STATS, bool SUSPEND, bool MANY>
-__device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, uint32_t* extBase, SceneHit& h, Trav& t, Stats& st)
+__device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, uint32_t* extBase, SceneHit& h, Trav& t, Stats& st,
+                                         const int keepAboveArg = -1)
 {
 #ifdef RT_LDS_NODE_FETCH
     /* 4 KB slab after [stack][pixel fields][mask extension]; wave-uniform address */
@@ -496,7 +497,9 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
     const DModel* __restrict__ models = a.models;
     const DPair* __restrict__ pairs = a.pairs;
     const DTri* __restrict__ tris = a.tris;
-    const int enteredNum = SUSPEND ? __popcll(__ballot(1)) * a.suspendNum : 0; /* a.suspendNum / RT_SUSPEND_DEN: 3/8 unless the launch tuner found 4/8 faster for this scene */
+    /* the loop runs while more than keepAbove lanes are still traversing: entered * a.suspendNum / RT_SUSPEND_DEN (3/8 unless the
+     * launch tuner found 4/8 faster for this scene) — or what the caller says (the queued-stages kernel, rt_kernels_q.h) */
+    const int enteredNum = keepAboveArg >= 0 ? keepAboveArg * RT_SUSPEND_DEN : SUSPEND ? __popcll(__ballot(1)) * a.suspendNum : 0;
     phase_mark<STATS>(st, PH_TRAVERSE_CALL);
     /* One kind of work per iteration, chosen for the whole wave: the kind most lanes are
      * waiting for (wave-uniform branch, so only that code is issued).  A lane deep inside
