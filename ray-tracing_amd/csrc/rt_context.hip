@@ -135,8 +135,19 @@ struct RtContext {
         int next = 0;          /* which candidate the next measured launch uses */
         struct Probe { hipEvent_t start = nullptr, stop = nullptr; int cand = 0, frames = 0; bool live = false; } probe[6];
     } tuner;
-    float* dStaging = nullptr; /* per-frame colours of a fused launch (rt_device.h, KArgs::staging) */
-    size_t stagingBytes = 0;
+    /* per-frame colours of a fused launch (rt_device.h, KArgs::staging): two slabs, so that consecutive fused launches
+     * can alternate between the context's two streams — launch k+1 starts while launch k drains (launch_frames) */
+    float* dStaging[2] = {nullptr, nullptr};
+    size_t stagingBytes[2] = {0, 0};
+    bool stagingUnavailable = false; /* the slab could not be allocated at this image size: fused launches go out frame by frame (cleared by rt_resize) */
+    int stagedNext = 0;              /* stream / slab of the next fused launch */
+    bool alternate = true;           /* RT_ALTERNATE=0: every fused launch on the main stream (round-3 behaviour) */
+    /* the accumulation buffer is added to in launch order whichever stream a launch runs on: evAccWriter[s] marks the last
+     * kernel on stream s that writes it; accWriterPending[s] = the other stream has not been ordered after it yet */
+    hipEvent_t evAccWriter[2] = {nullptr, nullptr};
+    bool accWriterPending[2] = {false, false};
+    bool accWriterFull[2] = {false, false}; /* that kernel touches every pixel (an accumulate kernel, a one-part frame); false = one half of a two-part frame */
+    int lastLaunched = 0;            /* frames the last launch_frames call really enqueued (flush_pending rolls back the rest) */
     void* dDisplay = nullptr;  /* scratch of the display pass, kept between calls (grows on demand) */
     size_t displayBytes = 0;
     hipEvent_t evStart = nullptr, evStop = nullptr;
@@ -171,6 +182,7 @@ static hipStream_t joined(RtContext* ctx)
         hipEventRecord(ctx->evJoin, ctx->sideStream);
         hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0);
         ctx->sideDirty = false;
+        ctx->accWriterPending[1] = false; /* whatever the side stream adds to the accumulation buffer now precedes the main stream's next kernel */
     }
     ctx->needFork = true;
     return ctx->stream;
@@ -231,6 +243,7 @@ static int stage_upload(RtContext* ctx, void* dst, const void* src, size_t bytes
 }
 
 static int launch_frames(RtContext* ctx, int frame0, int nFrames);
+static bool gpu_idle(RtContext* ctx);
 
 /* Launch the frames rt_render_frame held back.  Called first thing by every entry point that reads or changes
  * what those frames depend on, or that hands results to the host. */
@@ -240,8 +253,9 @@ static int flush_pending(RtContext* ctx)
     const int n = ctx->pending;
     ctx->pending = 0;
     hipSetDevice(ctx->device);
+    ctx->lastLaunched = 0;
     const int rc = launch_frames(ctx, ctx->frame - n, n);
-    if (rc != RT_OK) ctx->frame -= n; /* the held frames never ran: the frame counter says so (the caller may retry) */
+    if (rc != RT_OK) ctx->frame -= n - ctx->lastLaunched; /* the frames that never ran: the frame counter says so (the caller may retry them) */
     return rc;
 }
 #define RT_FLUSH(ctx)                         \
@@ -289,6 +303,8 @@ int rt_create(int device_id, RtContext** out)
         HIP_TRY(ctx, hipEventCreate(&ctx->evStop));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evAccWriter[0], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evAccWriter[1], hipEventDisableTiming));
         return RT_OK;
     };
     if (int rc = init()) { /* the message stays readable through rt_last_error(NULL) */
@@ -303,6 +319,7 @@ int rt_create(int device_id, RtContext** out)
     if (const char* t = getenv("RT_TWO_STREAMS")) ctx->twoStreams = atoi(t) != 0;
     if (const char* c = getenv("RT_COALESCE")) ctx->coalesce = atoi(c) != 0;
     if (const char* fg = getenv("RT_FRAME_GROUP")) ctx->frameGroupOverride = atoi(fg);
+    if (const char* al = getenv("RT_ALTERNATE")) ctx->alternate = atoi(al) != 0;
     if (const char* q = getenv("RT_QUEUED")) ctx->queued = atoi(q) != 0;
     if (const char* q = getenv("RT_Q_FLUSH")) ctx->qFlushMin = atoi(q);
     if (const char* q = getenv("RT_Q_REFILL")) ctx->qRefillMin = atoi(q);
@@ -341,7 +358,9 @@ void rt_destroy(RtContext* ctx)
     hipFree(ctx->dTileCost);
     hipFree(ctx->dTileOrder);
     hipFree(ctx->dDisplay);
-    hipFree(ctx->dStaging);
+    hipFree(ctx->dStaging[0]);
+    hipFree(ctx->dStaging[1]);
+    for (int i = 0; i < 2; i++) if (ctx->evAccWriter[i]) hipEventDestroy(ctx->evAccWriter[i]);
     hipFree(ctx->dPxCold);
     hipFree(ctx->dQRecords);
     for (auto& pr : ctx->tuner.probe) {
@@ -411,11 +430,13 @@ int rt_resize(RtContext* ctx, int width, int height)
     }
     ctx->boundFrame = ctx->boundAccum = nullptr;
     ctx->orderTiles = 0; /* tile costs belong to the old geometry */
-    if (ctx->dStaging && ctx->stagingBytes != (size_t)RT_MAX_FUSED_FRAMES * ctx->localRows * width * 16) {
-        hipFree(ctx->dStaging); /* sized for the old image (16 frames of it): re-made by the next fused launch */
-        ctx->dStaging = nullptr;
-        ctx->stagingBytes = 0;
-    }
+    for (int i = 0; i < 2; i++)
+        if (ctx->dStaging[i] && ctx->stagingBytes[i] != (size_t)RT_MAX_FUSED_FRAMES * ctx->localRows * width * 16) {
+            hipFree(ctx->dStaging[i]); /* sized for the old image (16 frames of it): re-made by the next fused launch */
+            ctx->dStaging[i] = nullptr;
+            ctx->stagingBytes[i] = 0;
+        }
+    ctx->stagingUnavailable = false;
     return RT_OK;
 }
 
@@ -619,6 +640,33 @@ static void make_filters(const RtModel* models, int n_models, const std::vector<
     }
     /* rays starting farther than this from the origin have coarser fp32 spacing than the margin allows for */
     *maxOrigin = (float)(8.0 * extent);
+}
+
+/* The device array behind KArgs::filters / filterPairs: the n DFilter records, then ceil(n / 2) pair records (two DFilter
+ * slots each) with the same boxes side by side for the packed root filter of rt_kernels.h. */
+static std::vector<DFilter> append_filter_pairs(const std::vector<DFilter>& f)
+{
+    const size_t n = f.size(), np = (n + 1) / 2;
+    std::vector<DFilter> out(n + 2 * np);
+    memset(out.data(), 0, out.size() * sizeof(DFilter));
+    for (size_t i = 0; i < n; i++) out[i] = f[i];
+    static_assert(sizeof(DFilter) == 32, "a pair record is two DFilter slots = sixteen dwords");
+    for (size_t p = 0; p < np; p++) {
+        float* q = reinterpret_cast<float*>(&out[n + 2 * p]);
+        for (int h = 0; h < 2; h++) {
+            const size_t m = 2 * p + h;
+            uint32_t always = 1u; /* a missing second model never reaches the mask (the kernel checks m + 1 < n) */
+            if (m < n) {
+                for (int d = 0; d < 3; d++) {
+                    q[2 * d + h] = f[m].bMin[d];
+                    q[6 + 2 * d + h] = f[m].bMax[d];
+                }
+                always = f[m].always;
+            }
+            memcpy(&q[12 + h], &always, 4);
+        }
+    }
+    return out;
 }
 
 /* Chunks of the two-level model hierarchy (rt_device.h, DChunk): only built for more than 64 models.
@@ -942,6 +990,7 @@ static int prepare_scene(RtContext* ctx, const RtModel* models, int n_models, co
     }
     make_filters(models, n_models, rootCodes, rootChildren, spheres, n_spheres, ps.filters, &ps.maxOrigin);
     make_chunks(ps.filters, ps.chunks, &ps.nFiltered, &ps.extWords);
+    ps.filters = append_filter_pairs(ps.filters); /* uploaded as one array */
     ps.pairs.swap(sb.pairs);
     ps.bigLeaves.swap(sb.bigLeaves);
     ps.hModels.assign(models, models + n_models);
@@ -1052,7 +1101,10 @@ int rt_update_models(RtContext* ctx, const RtModel* models, int n_models)
     if (matricesChanged) { /* the world-space root filter boxes depend on the matrices only */
         std::vector<DFilter> filters;
         make_filters(models, n_models, ctx->hRootCodes, ctx->hRootChildren, ctx->hSpheres.data(), (int)ctx->hSpheres.size(), filters, &ctx->filterMaxOrigin);
-        if ((rc = stage_upload(ctx, ctx->dFilters, filters.data(), sizeof(DFilter) * n_models))) return rc;
+        {
+            const std::vector<DFilter> up = append_filter_pairs(filters);
+            if ((rc = stage_upload(ctx, ctx->dFilters, up.data(), sizeof(DFilter) * up.size()))) return rc;
+        }
         if ((rc = refresh_chunks(ctx, filters))) return rc;
     }
     ctx->hModels.assign(models, models + n_models);
@@ -1082,7 +1134,10 @@ int rt_update_spheres(RtContext* ctx, const RtSphere* spheres, int n_spheres)
     if (ctx->nModels) { /* the filter margins scale with the scene extent, which includes the spheres */
         std::vector<DFilter> filters;
         make_filters(ctx->hModels.data(), ctx->nModels, ctx->hRootCodes, ctx->hRootChildren, spheres, n_spheres, filters, &ctx->filterMaxOrigin);
-        if ((rc = stage_upload(ctx, ctx->dFilters, filters.data(), sizeof(DFilter) * ctx->nModels))) return rc;
+        {
+            const std::vector<DFilter> up = append_filter_pairs(filters);
+            if ((rc = stage_upload(ctx, ctx->dFilters, up.data(), sizeof(DFilter) * up.size()))) return rc;
+        }
         if ((rc = refresh_chunks(ctx, filters))) return rc;
     }
     return RT_OK;
@@ -1138,6 +1193,7 @@ static void fill_args(RtContext* ctx, int frame0, int nFrames, KArgs& a)
     a.norms = ctx->dNorms;
     a.bigLeaves = ctx->dBigLeaves;
     a.filters = ctx->dFilters;
+    a.filterPairs = reinterpret_cast<const float*>(ctx->dFilters + ctx->nModels);
     a.chunks = ctx->dChunks;
     a.nChunks = ctx->nChunks;
     a.nFiltered = ctx->nFiltered;
@@ -1265,7 +1321,11 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
     }
     if (ctx->lptEnabled) {
         const long long f = ctx->framesSinceResize;
-        if (f >= ctx->nextSortAt) { /* re-sort once 1, 2, 4, 8, ... frames have been recorded */
+        /* re-sort once 1, 2, 4, 8, ... frames have been recorded.  The sort rewrites the order array the running kernels read,
+         * so it joins the two streams — and a join in the middle of back-to-back launches serialises the next launch behind the
+         * drain of the previous one (the driver's K = 20 run: 1 + 16 + 3 frames, the sort due at the 3-frame tail).  While the
+         * GPU is busy the sort therefore waits for the next launch that finds it idle, unless it is overdue by a factor of 4. */
+        if (f >= ctx->nextSortAt && (f >= 4 * ctx->nextSortAt || f < 8 || gpu_idle(ctx))) {
             while (ctx->nextSortAt <= f) ctx->nextSortAt *= 2;
             hipLaunchKernelGGL(rtk::rt_order_kernel, dim3(1), dim3(1024), 0, joined(ctx), ctx->dTileCost, ctx->dTileOrder, tiles);
             HIP_TRY(ctx, hipGetLastError());
@@ -1289,39 +1349,61 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
     /* several frames in one launch: (tile, frame) items, per-frame colours staged and summed in frame order afterwards */
     const bool staged = nFrames > 1;
     const size_t nPix = (size_t)ctx->localRows * ctx->W;
+    /* Fused launches alternate between the context's two streams (own streams only), each with its own staging slab: the
+     * trace kernel of launch k+1 — other frames, nothing shared but the scene — starts while launch k drains (a launch ends
+     * with waves retiring one by one for as long as one pixel chain lasts), and only the rt_accumulate_kernels, which add
+     * into the accumulation buffer in FRAME order, are chained by events. */
+    const bool twoOwn = ctx->twoStreams && ctx->stream == ctx->ownStream && ctx->sideStream;
+    const int lane = (staged && twoOwn && ctx->alternate) ? ctx->stagedNext : 0;
+    hipStream_t laneStream = lane ? ctx->sideStream : ctx->stream;
     if (staged) {
         const size_t need = (size_t)nFrames * nPix * 16;
-        if (ctx->stagingBytes < need) {
+        if (!ctx->stagingUnavailable && ctx->stagingBytes[lane] < need) {
             HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
-            hipFree(ctx->dStaging);
-            ctx->dStaging = nullptr;
-            ctx->stagingBytes = 0;
-            /* grow once to the largest batch; if memory is short, to this batch; if even that fails the frames go out
-             * one launch each (a single-frame launch needs no staging) — a render call never fails for want of scratch */
-            const size_t cap = (size_t)RT_MAX_FUSED_FRAMES * nPix * 16;
-            size_t got = cap;
-            if (hipMalloc(&ctx->dStaging, cap) != hipSuccess) {
-                (void)hipGetLastError();
-                ctx->dStaging = nullptr;
-                got = need;
-                if (hipMalloc(&ctx->dStaging, need) != hipSuccess) {
+            /* both slabs are made by the first fused launch (a warm-up launch then pays for both: an allocation of this size
+             * takes milliseconds); grow once to the largest batch; if memory is short, to this batch */
+            for (int sl = 0; sl < (twoOwn && ctx->alternate ? 2 : 1); sl++) {
+                const int b = sl == 0 ? lane : 1 - lane;
+                if (ctx->stagingBytes[b] >= need) continue;
+                hipFree(ctx->dStaging[b]);
+                ctx->dStaging[b] = nullptr;
+                ctx->stagingBytes[b] = 0;
+                const size_t cap = (size_t)RT_MAX_FUSED_FRAMES * nPix * 16;
+                size_t got = cap;
+                if (hipMalloc(&ctx->dStaging[b], cap) != hipSuccess) {
                     (void)hipGetLastError();
-                    ctx->dStaging = nullptr;
-                    if (ctx->lptEnabled) ctx->framesSinceResize -= nFrames; /* counted again by the single launches */
-                    for (int f = 0; f < nFrames; f++) {
-                        const int rc1 = launch_frames(ctx, frame0 + f, 1);
-                        if (rc1 != RT_OK) return rc1;
+                    ctx->dStaging[b] = nullptr;
+                    got = need;
+                    if (hipMalloc(&ctx->dStaging[b], need) != hipSuccess) {
+                        (void)hipGetLastError();
+                        ctx->dStaging[b] = nullptr;
+                        got = 0;
                     }
-                    return RT_OK;
                 }
+                ctx->stagingBytes[b] = got;
+                if (got < need && b != lane) ctx->alternate = false; /* no room for the second slab: fused launches stay on one stream */
             }
-            ctx->stagingBytes = got;
         }
-        a.staging = ctx->dStaging;
+        if (ctx->stagingUnavailable || ctx->stagingBytes[lane] < need) {
+            if (ctx->lptEnabled) ctx->framesSinceResize -= nFrames; /* counted again by the launches below */
+            if (lane == 1) { /* no room for the second slab: every fused launch on the main stream from now on */
+                ctx->alternate = false;
+                ctx->stagedNext = 0;
+                return launch_frames(ctx, frame0, nFrames);
+            }
+            /* not even one slab: the frames go out one launch each (a single-frame launch needs no staging) — a render
+             * call never fails for want of scratch — and the allocation is not tried again until the image is resized
+             * (every fused launch repeated two failing hipMallocs and a stream synchronise) */
+            ctx->stagingUnavailable = true;
+            for (int f = 0; f < nFrames; f++) {
+                const int rc1 = launch_frames(ctx, frame0 + f, 1); /* each counts itself in ctx->lastLaunched: a failure in the
+                                                                     * middle leaves the frame counter on the first frame not rendered */
+                if (rc1 != RT_OK) return rc1;
+            }
+            return RT_OK;
+        }
+        a.staging = ctx->dStaging[lane];
         a.stagingStride = (uint32_t)nPix;
-        /* the frames before this launch may have left a half-frame kernel on the side stream that still adds into
-         * the accumulation buffer: rt_accumulate_kernel must come after it */
-        (void)joined(ctx);
     }
     /* launch tuner: collect finished probes, pick this launch's threshold */
     RtContext::Tuner& tn = ctx->tuner;
@@ -1354,12 +1436,27 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
             }
         }
     }
-    const int parts = (!staged && ctx->twoStreams && ctx->stream == ctx->ownStream && ctx->sideStream && tiles >= 2) ? 2 : 1;
-    if (parts == 2 && ctx->needFork) { /* the side stream follows what the main stream holds so far */
+    const int parts = (!staged && twoOwn && tiles >= 2) ? 2 : 1;
+    if ((parts == 2 || lane == 1) && ctx->needFork) { /* the side stream follows what the main stream holds so far */
         HIP_TRY(ctx, hipEventRecord(ctx->evFork, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->sideStream, ctx->evFork, 0));
         ctx->needFork = false;
     }
+    /* a kernel that adds into the accumulation buffer (a single-frame trace kernel; the accumulate kernel of a fused
+     * launch) comes after the last such kernel on the OTHER stream; its own stream orders it after its predecessors */
+    /* (the halves of consecutive two-part frames need no such wait: between two sorts of the tile order a stream's half is the
+     * same set of pixels, and a sort joins the streams) */
+    auto order_acc_writer = [&](int s, bool full) -> int {
+        hipStream_t st = s ? ctx->sideStream : ctx->stream;
+        if (ctx->accWriterPending[1 - s] && (full || ctx->accWriterFull[1 - s])) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->evAccWriter[1 - s], 0));
+        return RT_OK;
+    };
+    auto mark_acc_writer = [&](int s, bool full) -> int {
+        HIP_TRY(ctx, hipEventRecord(ctx->evAccWriter[s], s ? ctx->sideStream : ctx->stream));
+        ctx->accWriterPending[s] = true;
+        ctx->accWriterFull[s] = full;
+        return RT_OK;
+    };
     for (int p = 0; p < parts; p++) {
         const int partTiles = (tiles - p + parts - 1) / parts;
         /* frames per item: 1 = the most items and the shortest tail.  The FLAT scenes' per-frame chains are short and
@@ -1379,38 +1476,58 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         const long long items = (long long)partTiles * a.frameGroups;
         int grid = (int)(resident < items ? resident : items);
         if (ctx->gridOverride > 0) grid = (int)(ctx->gridOverride < items ? ctx->gridOverride : items);
-        a.pxCold = (float4*)((char*)ctx->dPxCold + (size_t)p * ctx->pxColdWaves * RT_COLD_STRIDE_BYTES);
-#ifdef RT_QUEUED_EXPERIMENT
-        a.qRecords = queued ? (uint32_t*)ctx->dQRecords + (size_t)p * ctx->qWaves * RT_Q_WAVE_DWORDS : nullptr;
-#endif
         a.launchTiles = partTiles;
         a.launchItems = (int)items;
         a.orderOffset = p;
         a.orderStride = parts;
-        a.tileQueue = ctx->dTileQueue + p;
         /* One kernel alone: all its workgroups become resident at once, the first `grid` positions go
          * by blockIdx and only the rest through the queue.  Two kernels sharing the chip: workgroups
          * are dispatched as slots free up, possibly late, so every position — the longest chains
          * first — comes from the queue. */
         a.queueStart = parts == 2 ? 1 : 0;
-        a.tileQueueBase = ctx->tileQueueNext[p] - (a.queueStart ? 0ull : (unsigned long long)grid);
         if (ctx->verbose) fprintf(stderr, "[raytrace_hip] launch variant=%d part=%d/%d tiles=%d grid=%d perCU=%d lds=%zu\n", variant, p, parts, partTiles, grid, ctx->occPerCU[variant], stackBytes);
-        if (probe) hipEventRecord(probe->start, ctx->stream);
-        hipLaunchKernelGGL(parts == 2 ? kernHalf : kern, dim3(grid), dim3(RT_WAVE), stackBytes, p == 0 ? ctx->stream : ctx->sideStream, a);
-        if (probe) { hipEventRecord(probe->stop, ctx->stream); probe->live = true; }
+        /* stream, pixel-record slot and tile-queue counter of this kernel: part p of a two-part frame, or the fused launch's lane */
+        const int q = parts == 2 ? p : lane;
+        hipStream_t st = q ? ctx->sideStream : ctx->stream;
+        a.pxCold = (float4*)((char*)ctx->dPxCold + (size_t)q * ctx->pxColdWaves * RT_COLD_STRIDE_BYTES);
+#ifdef RT_QUEUED_EXPERIMENT
+        a.qRecords = queued ? (uint32_t*)ctx->dQRecords + (size_t)q * ctx->qWaves * RT_Q_WAVE_DWORDS : nullptr;
+#endif
+        a.tileQueue = ctx->dTileQueue + q;
+        a.tileQueueBase = ctx->tileQueueNext[q] - (a.queueStart ? 0ull : (unsigned long long)grid);
+        if (!staged) { /* the trace kernel itself adds into the accumulation buffer (RCC:20-23) */
+            const int orc = order_acc_writer(q, parts == 1);
+            if (orc) return orc;
+        }
+        if (probe) hipEventRecord(probe->start, st);
+        hipLaunchKernelGGL(parts == 2 ? kernHalf : kern, dim3(grid), dim3(RT_WAVE), stackBytes, st, a);
+        if (probe) { hipEventRecord(probe->stop, st); probe->live = true; }
         HIP_TRY(ctx, hipGetLastError()); /* a refused launch ran no wave: the device counter did not move */
         /* every tile not taken by blockIdx is one successful fetch, and each of the grid waves overshoots once */
-        ctx->tileQueueNext[p] += (unsigned long long)items + (a.queueStart ? (unsigned long long)grid : 0ull);
-        if (p == 1) ctx->sideDirty = true;
+        ctx->tileQueueNext[q] += (unsigned long long)items + (a.queueStart ? (unsigned long long)grid : 0ull);
+        if (q == 1) ctx->sideDirty = true;
+        if (!staged) {
+            const int mrc = mark_acc_writer(q, parts == 1);
+            if (mrc) return mrc;
+        }
     }
+    if (!staged && parts == 1) ctx->accWriterPending[1] = false; /* ordered before the main stream's kernel just launched */
     if (staged) {
         int blocks = (int)((nPix + 255) / 256);
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(rtk::rt_accumulate_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const float4*)ctx->dStaging, nFrames, nPix, (float4*)a.accumulated,
+        /* RCC:18-23 for this launch's frames, after every earlier frame's: the other stream's last writer is waited for */
+        const int orc = order_acc_writer(lane, true);
+        if (orc) return orc;
+        hipLaunchKernelGGL(rtk::rt_accumulate_kernel, dim3(blocks), dim3(256), 0, laneStream, (const float4*)ctx->dStaging[lane], nFrames, nPix, (float4*)a.accumulated,
                            (float4*)a.frameRender, nPix);
         HIP_TRY(ctx, hipGetLastError());
+        const int mrc = mark_acc_writer(lane, true);
+        if (mrc) return mrc;
+        ctx->accWriterPending[1 - lane] = false; /* this accumulate is ordered after it; later writers wait for this one */
+        if (twoOwn && ctx->alternate) ctx->stagedNext = 1 - lane;
     }
     ctx->pixelFrames += (uint64_t)ctx->localRows * ctx->W * nFrames;
+    ctx->lastLaunched += nFrames;
     return RT_OK;
 }
 

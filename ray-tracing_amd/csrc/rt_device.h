@@ -116,6 +116,8 @@ struct KArgs {
     const DTriN* norms;
     const uint32_t* bigLeaves;   /* pairs of (start, count) */
     const DFilter* filters;      /* one per model */
+    const float* filterPairs;    /* the same boxes two models side by side (minx0 minx1 miny0 miny1 minz0 minz1 maxx0 ... always0 always1 - -),
+                                  * sixteen dwords per pair, behind the DFilter array: the packed two-models-per-step root filter */
     float filterMaxOrigin;       /* ray origins farther than this from 0 skip the filter */
     int32_t nSpheres, nModels;
     /* models [0, nFiltered) go through the conservative filter.  nModels <= 64: bit m of the lane's 64-bit

@@ -424,8 +424,48 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
             }
             return keep;
         };
-        if (!MANY) { /* up to 64 models: one lockstep loop, bit m = model m */
+#ifdef RT_NO_PACKED_FILTER /* A/B build (make EXTRA=-DRT_NO_PACKED_FILTER): one model per step */
+        if (!MANY) {
+#else
+        if (!MANY && STATS) { /* up to 64 models: one lockstep loop, bit m = model m (with the audits) */
+#endif
             for (int m = 0; m < nf; m++) cand |= (test_model(m) ? 1ull : 0ull) << m;
+        } else if (!MANY) {
+            /* The shipped form of the same loop, TWO models per step (round 4): the boxes sit in SGPRs, and a VALU instruction
+             * with an SGPR source issues at the slow rate on gfx950 while v_pk_add/mul_f32 take an SGPR PAIR for the price of one
+             * (the two-spheres-per-step pre-test above, profiles/r03_valu_op_rates.txt).  The pair records (rt_context.hip,
+             * append_filter_pairs) hold the two models' boxes side by side — minx0 minx1 miny0 miny1 ... — so that one scalar load
+             * fills the pairs and the twelve (b - o) and twelve (.) * (1 / d) of two slab tests are twelve packed instructions.
+             * Same operations on the same values per model: the candidate masks are those of the loop above. */
+            typedef float rt_f2v __attribute__((ext_vector_type(2)));
+            const rt_f2v px = {rpos.x, rpos.x}, py = {rpos.y, rpos.y}, pz = {rpos.z, rpos.z};
+            const rt_f2v ix = {winv.x, winv.x}, iy = {winv.y, winv.y}, iz = {winv.z, winv.z};
+            const RT_CAS float* fp = (const RT_CAS float*)a.filterPairs;
+            /* (the halves of a packed product reach fminf / fmaxf as "maybe a signalling NaN" and would each be canonicalised
+             * first — six more instructions per model than the packing saves — so the slab test's min / max are written as the
+             * instructions themselves; products of finite or infinite operands are never signalling NaNs) */
+            auto keep_of = [&](float t0x, float t1x, float t0y, float t1y, float t0z, float t1z, uint32_t always) -> bool {
+                float nx, ny, nz, fx, fy, fz, tNear, tFar;
+                asm("v_min_f32 %0, %1, %2" : "=v"(nx) : "v"(t0x), "v"(t1x));
+                asm("v_min_f32 %0, %1, %2" : "=v"(ny) : "v"(t0y), "v"(t1y));
+                asm("v_min_f32 %0, %1, %2" : "=v"(nz) : "v"(t0z), "v"(t1z));
+                asm("v_max_f32 %0, %1, %2" : "=v"(fx) : "v"(t0x), "v"(t1x));
+                asm("v_max_f32 %0, %1, %2" : "=v"(fy) : "v"(t0y), "v"(t1y));
+                asm("v_max_f32 %0, %1, %2" : "=v"(fz) : "v"(t0z), "v"(t1z));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tNear) : "v"(nx), "v"(ny), "v"(nz));
+                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tFar) : "v"(fx), "v"(fy), "v"(fz));
+                const bool hit = tFar >= tNear && tFar > 0.0f;
+                const bool near = hit && (tNear > 0.0f ? tNear : 0.0f) <= h.dst; /* box_dst(...) < inf && box_dst(...) <= h.dst */
+                return near | farOrigin | (always != 0u);
+            };
+            for (int m = 0; m < nf; m += 2) {
+                const RT_CAS float* q = fp + 8 * m; /* pair record m / 2, sixteen dwords */
+                const rt_f2v t0x = (rt_f2v{q[0], q[1]} - px) * ix, t0y = (rt_f2v{q[2], q[3]} - py) * iy, t0z = (rt_f2v{q[4], q[5]} - pz) * iz;
+                const rt_f2v t1x = (rt_f2v{q[6], q[7]} - px) * ix, t1y = (rt_f2v{q[8], q[9]} - py) * iy, t1z = (rt_f2v{q[10], q[11]} - pz) * iz;
+                const bool keep0 = keep_of(t0x.x, t1x.x, t0y.x, t1y.x, t0z.x, t1z.x, __float_as_uint(q[12]));
+                const bool keep1 = (m + 1 < nf) && keep_of(t0x.y, t1x.y, t0y.y, t1y.y, t0z.y, t1z.y, __float_as_uint(q[13]));
+                cand |= ((keep0 ? 1ull : 0ull) << m) | ((keep1 ? 1ull : 0ull) << (m + 1));
+            }
         } else {
             /* more than 64 models: chunk boxes first (a chunk no lane of the wave hits costs one box test instead of
              * 16), candidates beyond model 62 go to the lane's LDS extension words */
