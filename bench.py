@@ -52,6 +52,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK = 256 * 4 * 2.4e9 / 2.0          # wave64 VALU instructions / s: 256 CUs x 4 SIMD-32, 2 cycles each
+N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9
 KERNEL_LIKE = "%rt_trace%kernel<false%"    # the non-stats instantiations (whole-frame and half-frame names)
 
 
@@ -71,6 +72,28 @@ def spawn_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+def pin_to_gpu_numa_node(torch, dev_index):
+    """One process per GPU: keep this rank's host threads on the cores of its GPU's NUMA node (the launch calls and the
+    gather's staging then stay on the socket the GPU hangs off).  Best effort: returns the CPU list used, or None."""
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)  # torch exposes PCI domain / bus / device as integers
+        bdf = "%04x:%02x:%02x.0" % (int(getattr(pr, "pci_domain_id", 0)), int(pr.pci_bus_id), int(pr.pci_device_id))
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return f"numa node {node}: {len(cpus)} cpus"
+    except Exception:
+        return None
 
 
 def cpu_baseline(pkg, scene_id, width, height, min_s=10.0, max_frames=4, threads=1):
@@ -222,11 +245,19 @@ def collect_pmc(config, steps, warmup, with_traffic, fpl=16):
         r = {"valu_insts_per_launch": sq["SQ_INSTS_VALU"]["avg"],
              "lane_util": sq["SQ_THREAD_CYCLES_VALU"]["avg"] / (64.0 * sq["SQ_ACTIVE_INST_VALU"]["avg"]),
              "launches_sampled": sq["SQ_INSTS_VALU"]["n"]}
+        # dynamic VALU instruction types (two passes: the SQ block counts up to 8 at a time, kept small for safety)
+        m1 = run_pmc_pass(["SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32"], config, steps, warmup, out, "m1", fpl)
+        m2 = run_pmc_pass(["SQ_INSTS_VALU", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT"], config, steps, warmup, out, "m2", fpl)
+        if m1 and m2 and "SQ_INSTS_VALU_TRANS_F32" in m1 and "SQ_INSTS_VALU_CVT" in m2:
+            r["valu_types"] = {"arith": m1["SQ_INSTS_VALU_ADD_F32"]["avg"] + m1["SQ_INSTS_VALU_MUL_F32"]["avg"] + m1["SQ_INSTS_VALU_FMA_F32"]["avg"],
+                               "trans": m1["SQ_INSTS_VALU_TRANS_F32"]["avg"], "int32": m2["SQ_INSTS_VALU_INT32"]["avg"],
+                               "int64": m2["SQ_INSTS_VALU_INT64"]["avg"], "cvt": m2["SQ_INSTS_VALU_CVT"]["avg"]}
         if with_traffic:
             rd = run_pmc_pass(["FETCH_SIZE"], config, steps, warmup, out, "rd", fpl)
             wr = run_pmc_pass(["WRITE_SIZE"], config, steps, warmup, out, "wr", fpl)
             if rd and wr and "FETCH_SIZE" in rd and "WRITE_SIZE" in wr:
-                # MI355X_MICROARCH.md §HBM: KiB units; gfx950 FETCH_SIZE counts wide coalesced reads at 1/2 -> x2; WRITE_SIZE as is
+                # MI355X_MICROARCH.md §HBM: KiB units; gfx950 FETCH_SIZE adds 64 B per 128-B line fill -> x2, calibrated for streaming AND
+                # for the traversal's divergent 64-B / 48-B per-lane record fetches (profiles/r04_fetch_size_calibration.txt); WRITE_SIZE as is
                 r["hbm_read_bytes"] = rd["FETCH_SIZE"]["avg"] * 1024 * 2
                 r["hbm_write_bytes"] = wr["WRITE_SIZE"]["avg"] * 1024
         return r
@@ -242,9 +273,12 @@ def replayed_pmc(config, fpl=16):
         p = json.load(f).get(f"config{config}_n1")
     if not p or p.get("frames_per_launch", 1) != fpl:
         return None
-    return {"valu_insts_per_launch": p["valu_insts"], "lane_util": p["valu_lane_utilisation"],
-            "hbm_read_bytes": p.get("read_bytes"), "hbm_write_bytes": p.get("write_bytes"),
-            "replayed_from": "profiles/pmc_summary.json (" + p.get("source", "?") + ")"}
+    r = {"valu_insts_per_launch": p["valu_insts"], "lane_util": p["valu_lane_utilisation"],
+         "hbm_read_bytes": p.get("read_bytes"), "hbm_write_bytes": p.get("write_bytes"),
+         "replayed_from": "profiles/pmc_summary.json (" + p.get("source", "?") + ")"}
+    if p.get("valu_types"):
+        r["valu_types"] = p["valu_types"]
+    return r
 
 
 def launch_profile(pkg, api, dev_index, scene_id, W, H, launches, frames_per_launch, partition=None):
@@ -278,7 +312,32 @@ def launch_profile(pkg, api, dev_index, scene_id, W, H, launches, frames_per_lau
     return c["gpuMs"] / launches, c["segments"] / launches
 
 
-def valu_roofline(pmc, launch_ms, segments_per_launch):
+def peak_at_mix(pmc, variant):
+    """The VALU issue rate this kernel could reach if nothing but VALU issue limited it, AT ITS OWN INSTRUCTION MIX: the 2-cycle
+    wave64 rate behind `peak` holds for fp32 add / mul / fma on VGPR operands only (profiles/r03_valu_op_rates.txt).  Dynamic
+    instruction types come from the hardware (SQ_INSTS_VALU_ADD/MUL/FMA_F32, _TRANS_F32, _INT32, _INT64, _CVT; the rest = moves, logic,
+    compares, selects, min / max); the cost of each bucket = its static class make-up in the kernel's ISA (tools/isa_mix.py ->
+    profiles/isa_mix.json: which adds carry an SGPR source, which integer / other instructions are base class)."""
+    types = pmc.get("valu_types")
+    path = os.path.join(ROOT, "profiles", "isa_mix.json")
+    if not types or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        mix = json.load(f).get(variant)
+    if not mix:
+        return None
+    total = pmc["valu_insts_per_launch"]
+    counts = dict(types)
+    counts["other"] = max(0.0, total - sum(types.values()))
+    cpi = mix["cycles_per_instruction"]
+    cycles = sum(counts[b] * cpi.get(b, mix["static_cycles_per_instruction"]) for b in counts)
+    cpi_mix = cycles / max(1.0, total)
+    return {"cycles_per_valu_inst_at_mix": cpi_mix, "peak_at_mix": N_SIMD * CLOCK_HZ / cpi_mix / 1e9,
+            "valu_type_shares": {b: counts[b] / max(1.0, total) for b in counts},
+            "bucket_cycles_per_inst": {b: cpi.get(b) for b in counts}}
+
+
+def valu_roofline(pmc, launch_ms, segments_per_launch, variant="bvh"):
     achieved = pmc["valu_insts_per_launch"] / (launch_ms * 1e-3)
     r = {"bound": "valu", "achieved": achieved / 1e9, "peak": VALU_PEAK / 1e9, "unit": "Gwave-inst/s",
          "lane_util": pmc["lane_util"], "frac": achieved / VALU_PEAK * pmc["lane_util"],
@@ -286,6 +345,15 @@ def valu_roofline(pmc, launch_ms, segments_per_launch):
          "valu_insts_per_segment": pmc["valu_insts_per_launch"] / max(1, segments_per_launch),
          "counters": "replayed: " + pmc["replayed_from"] if "replayed_from" in pmc else
                      f"rocprofv3 --pmc passes over a child run of this script, in this invocation ({pmc.get('launches_sampled')} launches)"}
+    pm = peak_at_mix(pmc, variant)
+    if pm:
+        # frac_at_mix = share of the VALU issue capacity AT THIS MIX that the kernel uses: ~1 means the VALU pipes are saturated and
+        # only fewer instructions (or more useful lanes per instruction: lane_util) can make it faster
+        r.update({"peak_at_mix": pm["peak_at_mix"], "cycles_per_valu_inst_at_mix": pm["cycles_per_valu_inst_at_mix"],
+                  "valu_busy_at_mix": achieved / 1e9 / pm["peak_at_mix"], "frac_at_mix": achieved / 1e9 / pm["peak_at_mix"] * pmc["lane_util"],
+                  "valu_type_shares": pm["valu_type_shares"],
+                  "peak_at_mix_derivation": "1024 SIMD x 2.4 GHz / sum over hardware-counted instruction types of (share x cycles per wave64 instruction of that "
+                                            "type's static class make-up in this kernel: profiles/isa_mix.json, profiles/r03_valu_op_rates.txt)"})
     if pmc.get("hbm_read_bytes") is not None and pmc.get("hbm_write_bytes") is not None:
         r["traffic"] = pmc["hbm_read_bytes"] + pmc["hbm_write_bytes"]
         r["hbm_physical"] = {"bytes_per_launch": r["traffic"], "GBps": r["traffic"] / (launch_ms * 1e-3) / 1e9,
@@ -331,6 +399,7 @@ def main():
     dev_index = 0 if os.environ.get("RT_BENCH_ONE_DEVICE") else local_rank
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(dev_index)
+    pinned_cpus = pin_to_gpu_numa_node(torch, dev_index) if world > 1 and not os.environ.get("RT_BENCH_ONE_DEVICE") else None
     device = torch.device("cuda", dev_index)
     comm_device = device if backend == "nccl" else torch.device("cpu")
     if world > 1:
@@ -500,7 +569,8 @@ def main():
         props = torch.cuda.get_device_properties(dev_index)
         me = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "name": props.name,
               "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
-              "pci_device_id": getattr(props, "pci_device_id", None), "pid": os.getpid(), "backend": dist.get_backend()}
+              "pci_device_id": getattr(props, "pci_device_id", None), "pid": os.getpid(), "backend": dist.get_backend(),
+              "pinned_cpus": pinned_cpus}
         devices_seen = [None] * world
         dist.all_gather_object(devices_seen, me)
 
@@ -533,7 +603,7 @@ def main():
             pmc = replayed_pmc(args.config, fpl)
         roof = None
         if pmc is not None:
-            roof = valu_roofline(pmc, launch_ms, launch_segments)
+            roof = valu_roofline(pmc, launch_ms, launch_segments, "flat" if args.config <= 2 else "bvh")
             roof["frames_per_launch"] = fpl
             roof["kernel"] = (f"rt_trace_kernel<false, *>, launches of {fpl} frames ((tile, frame) work items; one kernel per launch on one "
                               "stream in the roofline pass) — the form the timed K back-to-back rt_render_frame calls are launched in")
@@ -542,6 +612,11 @@ def main():
                 "what": "SURVEY.md 8(d) algorithmic bytes (the reference loop's loads for the counted work) / launch time; the scene is "
                         "SGPR/L2 resident, so this is NOT a roof and may exceed 8 TB/s — kept for continuity with round 1",
                 "bytes_per_launch": my_bytes * fpl, "GBps": my_bytes * fpl / (launch_ms * 1e-3) / 1e9}
+            roof["secondary_hbm_algorithmic"]["frac_of_peak"] = roof["secondary_hbm_algorithmic"]["GBps"] / HBM_PEAK_GBS
+            # more than the memory system can move: the figure describes the REFERENCE's loads, most of which are SGPR / cache hits here
+            roof["secondary_hbm_algorithmic"]["void"] = roof["secondary_hbm_algorithmic"]["frac_of_peak"] > 1.0
+            roof["fetch_size_factor"] = {"factor": 2.0, "calibration": "profiles/r04_fetch_size_calibration.txt (streaming and divergent 64-B / 48-B per-lane "
+                                                                       "record fetches: FETCH_SIZE adds 64 B per 128-B line fill)"}
         parity = parity_check(pkg, api, dev_index, args.config, W, H, (3, H // 16, H // 8 - 2)) if world == 1 else None
         out = {
             "metric": f"Mrays/s at {W}x{H}, {spp} spp, {mb} bounces; per-channel L2 vs reference",
@@ -608,12 +683,19 @@ def main():
             nthr = min(os.cpu_count() or 1, 64)
             if nthr > 1:
                 out["cpu_baseline_threads"] = cpu_baseline(pkg, args.config, W, H, min_s=4.0, max_frames=64, threads=nthr)
+        if diagnostics_all:
+            # a segment-count disagreement between the passes is what the lost-counter race of round 2 looked like: the line is
+            # still printed (with its diagnostics), but it carries no headline value and the run fails
+            out["value_unchecked"] = out["value"]
+            out["value"] = None
         print(json.dumps(out), flush=True)
 
     tracer.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if diagnostics_all:
+        raise SystemExit("bench.py: diagnostics present: " + "; ".join(diagnostics_all))
 
 
 def run():

@@ -163,6 +163,7 @@ namespace RayTraceHost
         [DllImport(Lib)] public static extern int rt_gather_accumulated(IntPtr multi, [Out] float[] rgba, UIntPtr bytes);
         [DllImport(Lib)] public static extern int rt_multi_get_counters(IntPtr multi, out RtCounters c);
         [DllImport(Lib)] public static extern double rt_multi_last_gather_ms(IntPtr multi);
+        [DllImport(Lib)] public static extern int rt_multi_peer_access(IntPtr multi, out int pairs, out int enabled);
         [DllImport(Lib)] public static extern int rt_gather_accumulated_to_device(IntPtr multi, int root, IntPtr d_rgba, UIntPtr bytes);
         [DllImport(Lib)] public static extern int rt_gather_frame_to_device(IntPtr multi, int root, IntPtr d_rgba, UIntPtr bytes);
         [DllImport(Lib)] public static extern void rt_build_bvh_gpu_release();

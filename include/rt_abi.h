@@ -296,6 +296,10 @@ int rt_gather_accumulated_to_device(RtMulti* m, int root, void* d_rgba, size_t b
 int rt_gather_frame_to_device(RtMulti* m, int root, void* d_rgba, size_t bytes);
 /* Wall time of the last gather (copies + scatter, after the flush), milliseconds. */
 double rt_multi_last_gather_ms(const RtMulti* m);
+/* How copies between this multi-context's GPUs travel (peer access is checked and enabled by rt_create_multi): returns 2 = every
+ * pair of distinct devices has direct peer access (xGMI / PCIe P2P), 1 = some, 0 = none (hipMemcpyPeerAsync then stages through
+ * host memory: correct, slower), -1 = a single device; *pairs / *enabled (optional) receive the ordered-pair counts. */
+int rt_multi_peer_access(const RtMulti* m, int* pairs, int* enabled);
 /* Sum of the contexts' counters (gpuMs: the maximum). */
 int rt_multi_get_counters(RtMulti* m, RtCounters* out);
 
@@ -340,8 +344,9 @@ int rt_build_bvh_gpu(int device_id, const float* verts, const float* normals, in
                      const int32_t* indices, int n_indices, int quality,
                      RtBVHNode* out_nodes, int* out_n_nodes,
                      RtTriangle* out_tris, RtBvhStats* out_stats);
-/* rt_build_bvh_gpu keeps its device scratch between calls of the same thread (a scene build calls it once per mesh;
- * at most 4 GiB is kept, larger builds free it on return).  This frees it now. */
+/* rt_build_bvh_gpu keeps its device scratch between calls (a scene build calls it once per mesh; at most 4 GiB is kept,
+ * larger builds free it on return).  The scratch is ONE pool for the process: builds from several threads are serialised on
+ * it, and this call frees it whichever thread built last. */
 void rt_build_bvh_gpu_release(void);
 /* RCM:183-190 UpdateCameraParams: fills viewParams from (fovDeg, aspect, focusDist). */
 int rt_camera_view_params(float fov_deg, float aspect, float focus_distance, float out_view_params[3]);

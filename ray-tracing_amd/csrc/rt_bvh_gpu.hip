@@ -30,6 +30,7 @@
 
 #include <chrono>
 #include <thread>
+#include <mutex>
 #include <vector>
 
 #include "../../include/rt_abi.h"
@@ -501,8 +502,8 @@ __global__ void k_tri_index(const GTri* tris, int ntri, int* out)
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    /* no destructor: the pool below is thread-local, and a hipFree at thread or process exit may run after the HIP
-     * runtime is gone; rt_build_bvh_gpu_release() frees it explicitly, the process's teardown frees the rest */
+    /* no destructor: a hipFree at process exit may run after the HIP runtime is gone; rt_build_bvh_gpu_release() frees the
+     * pool explicitly, the process's teardown frees the rest */
     void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
     template <typename T>
     T* get(size_t n)
@@ -529,7 +530,11 @@ struct DevBuf {
 static inline int blocks(size_t n, int t = 256) { return (int)((n + t - 1) / t); }
 
 struct Pool { int device = -1; DevBuf b[22]; };
-static thread_local Pool g_pool;
+/* ONE pool for the process, used under g_poolMutex (round 4, ADVICE r3: the pool was thread_local, so every short-lived worker
+ * thread of a host that builds meshes on a thread pool left up to 4 GiB of device memory behind, and rt_build_bvh_gpu_release only
+ * reached the calling thread's).  Builds from several threads therefore run one after the other — each one fills the GPU anyway. */
+static Pool g_pool;
+static std::mutex g_poolMutex;
 static const size_t GB_POOL_KEEP = (size_t)4 << 30; /* scratch kept between calls: at most 4 GiB of the 288 (a 1.3M-triangle mesh needs ~1.5 GiB) */
 
 static void pool_release()
@@ -798,6 +803,7 @@ static int build_impl(int device, const float* verts, const float* normals, int 
 int build(int device, const float* verts, const float* normals, int n_verts, const int32_t* indices, int n_indices, int quality,
           RtBVHNode* out_nodes, int* out_n_nodes, RtTriangle* out_tris, RtBvhStats* out_stats)
 {
+    std::lock_guard<std::mutex> poolLock(g_poolMutex);
     int prev = -1;
     const bool havePrev = hipGetDevice(&prev) == hipSuccess; /* the caller's current device is the caller's business: put it back */
     if (out_n_nodes) *out_n_nodes = 0;                       /* every error path leaves 0 nodes */
@@ -812,7 +818,11 @@ int build(int device, const float* verts, const float* normals, int n_verts, con
 
 } // namespace gbvh
 
-extern "C" void rt_build_bvh_gpu_release(void) { gbvh::pool_release(); }
+extern "C" void rt_build_bvh_gpu_release(void)
+{
+    std::lock_guard<std::mutex> poolLock(gbvh::g_poolMutex);
+    gbvh::pool_release();
+}
 
 extern "C" int rt_build_bvh_gpu(int device_id, const float* verts, const float* normals, int n_verts, const int32_t* indices, int n_indices,
                                 int quality, RtBVHNode* out_nodes, int* out_n_nodes, RtTriangle* out_tris, RtBvhStats* out_stats)

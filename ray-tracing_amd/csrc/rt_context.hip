@@ -1257,7 +1257,7 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
     const size_t slabBytes = 0;
 #endif
     const size_t coldBytes = ctx->flatScene ? (size_t)2 * RT_WAVE * 16 : 0; /* the FLAT variant keeps its pixel records in LDS (rt_kernels.h, PX_COLD) */
-    const size_t stackBytes = (size_t)(ctx->stackEntries + RT_PIXEL_FIELDS + (ctx->extWords ? 1 + ctx->extWords : 0)) * RT_WAVE * sizeof(uint32_t) + slabBytes + coldBytes;
+    const size_t stackBytes = (size_t)(ctx->stackEntries + RT_PIXEL_FIELDS + (ctx->extWords ? 2 + ctx->extWords : 0)) * RT_WAVE * sizeof(uint32_t) + slabBytes + coldBytes; /* mask extension: summary + words + the MANY variant's bounce row */
     a.stackEntries = ctx->stackEntries;
     const bool many = ctx->nChunks > 0 && !ctx->flatScene;
     void (*kern)(const KArgs) = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_kernel<true, true> : rtk::rt_trace_kernel<false, true>)
@@ -1884,6 +1884,10 @@ struct RtMulti {
     void* pinned = nullptr;
     size_t pinnedBytes = 0;
     double lastGatherMs = 0;
+    /* peer access between the distinct devices of this multi-context (hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess at
+     * creation): peerPairs = ordered pairs of distinct devices, peerEnabled = of those, the pairs with direct access (xGMI or
+     * PCIe P2P).  Without it hipMemcpyPeerAsync still works — the runtime stages through host memory — only slower. */
+    int peerPairs = 0, peerEnabled = 0;
 };
 
 /* launch what every context holds back BEFORE waiting for any of them: a per-context synchronise in a loop would start
@@ -1895,6 +1899,17 @@ static int multi_flush_all(RtMulti* m)
         if (rc != RT_OK) return rc;
     }
     return RT_OK;
+}
+
+/* wait for whatever the contexts' streams hold (error paths of the gathers: nothing may still be writing into the caller's
+ * buffer when an error is returned) */
+static void multi_drain(RtMulti* m)
+{
+    for (RtContext* c : m->ctx) {
+        if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); continue; }
+        (void)hipStreamSynchronize(joined(c));
+        (void)hipGetLastError();
+    }
 }
 
 int rt_create_multi(const int* device_ids, int n_devices, RtMulti** out)
@@ -1914,8 +1929,40 @@ int rt_create_multi(const int* device_ids, int n_devices, RtMulti** out)
         }
         m->ctx.push_back(c);
     }
+    /* direct device-to-device copies (scene replication at upload, rt_gather_*_to_device) need peer access enabled in both
+     * directions; "already enabled" is fine, "cannot" leaves the pair on the runtime's host-staged path */
+    for (int i = 0; i < n_devices; i++)
+        for (int j = 0; j < n_devices; j++) {
+            const int di = m->ctx[i]->device, dj = m->ctx[j]->device;
+            if (di == dj) continue;
+            bool seen = false; /* the same pair listed twice (virtual shards on one device list) counts once */
+            for (int i2 = 0; i2 < n_devices && !seen; i2++)
+                for (int j2 = 0; j2 < n_devices && !seen; j2++)
+                    if ((i2 < i || (i2 == i && j2 < j)) && m->ctx[i2]->device == di && m->ctx[j2]->device == dj) seen = true;
+            if (seen) continue;
+            m->peerPairs++;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, di, dj) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+            if (!can) continue;
+            if (hipSetDevice(di) != hipSuccess) { (void)hipGetLastError(); continue; }
+            const hipError_t e = hipDeviceEnablePeerAccess(dj, 0);
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) m->peerEnabled++;
+            (void)hipGetLastError();
+        }
     *out = m;
     return RT_OK;
+}
+
+/* How device-to-device copies between this multi-context's GPUs travel: 2 = every pair of distinct devices has direct peer access
+ * (xGMI / PCIe P2P), 1 = some pairs, 0 = none (the runtime stages through host memory), -1 = one device only (nothing to copy
+ * between devices).  *pairs / *enabled (optional) receive the counts. */
+int rt_multi_peer_access(const RtMulti* m, int* pairs, int* enabled)
+{
+    if (!m) return RT_ERR_INVALID_ARG;
+    if (pairs) *pairs = m->peerPairs;
+    if (enabled) *enabled = m->peerEnabled;
+    if (m->peerPairs == 0) return -1;
+    return m->peerEnabled == m->peerPairs ? 2 : (m->peerEnabled > 0 ? 1 : 0);
 }
 
 void rt_destroy_multi(RtMulti* m)
@@ -2010,8 +2057,12 @@ static int multi_gather(RtMulti* m, float* rgba, size_t bytes, bool accumulated)
         const size_t n = (size_t)c->localRows * rowBytes;
         if (n) {
             const float* src = accumulated ? (c->boundAccum ? c->boundAccum : c->ownAccum) : (c->boundFrame ? c->boundFrame : c->ownFrame);
-            HIP_TRY(c, hipSetDevice(c->device));
-            HIP_TRY(c, hipMemcpyAsync((char*)m->pinned + off, src, n, hipMemcpyDeviceToHost, joined(c)));
+            hipError_t e = hipSetDevice(c->device);
+            if (e == hipSuccess) e = hipMemcpyAsync((char*)m->pinned + off, src, n, hipMemcpyDeviceToHost, joined(c));
+            if (e != hipSuccess) { /* copies already enqueued still write into m->pinned: wait for them before handing the error back */
+                multi_drain(m);
+                return fail(c, RT_ERR_HIP, "rt_gather: %s", hipGetErrorString(e));
+            }
         }
         off += n;
     }
@@ -2049,22 +2100,27 @@ static int multi_gather_device(RtMulti* m, int root, void* d_rgba, size_t bytes,
     if (!d_rgba || bytes != (size_t)W * H * 16) return fail(c0, RT_ERR_INVALID_ARG, "rt_gather_*_to_device: bytes %zu != H*W*16 = %zu", bytes, (size_t)W * H * 16);
     const size_t rowBytes = (size_t)W * 16;
     const int rootDev = m->ctx[root]->device;
+    for (RtContext* c : m->ctx) /* before anything is enqueued */
+        if (c->W != W || c->H != H) return fail(c0, RT_ERR_STATE, "rt_gather: contexts disagree on the resolution");
     int rc = multi_flush_all(m);
     if (rc) return rc;
     const auto t0 = std::chrono::steady_clock::now();
     for (RtContext* c : m->ctx) {
-        if (c->W != W || c->H != H) return fail(c0, RT_ERR_STATE, "rt_gather: contexts disagree on the resolution");
         const int rows = c->localRows;
         if (!rows) continue;
         const char* src = (const char*)(accumulated ? (c->boundAccum ? c->boundAccum : c->ownAccum) : (c->boundFrame ? c->boundFrame : c->ownFrame));
-        HIP_TRY(c, hipSetDevice(c->device));
+        hipError_t e = hipSetDevice(c->device);
         hipStream_t st = joined(c);
-        for (int l = 0; l < rows;) { /* a strip's rows are contiguous in the packed tile and in the image */
+        for (int l = 0; l < rows && e == hipSuccess;) { /* a strip's rows are contiguous in the packed tile and in the image */
             const int g = rt_local_to_global_row(c, l);
             int run = c->stripRows - (g % c->stripRows);
             if (run > rows - l) run = rows - l;
-            HIP_TRY(c, hipMemcpyPeerAsync((char*)d_rgba + (size_t)g * rowBytes, rootDev, src + (size_t)l * rowBytes, c->device, (size_t)run * rowBytes, st));
+            e = hipMemcpyPeerAsync((char*)d_rgba + (size_t)g * rowBytes, rootDev, src + (size_t)l * rowBytes, c->device, (size_t)run * rowBytes, st);
             l += run;
+        }
+        if (e != hipSuccess) { /* earlier contexts' copies into the caller's buffer are still in flight: wait before returning */
+            multi_drain(m);
+            return fail(c, RT_ERR_HIP, "rt_gather_*_to_device: %s", hipGetErrorString(e));
         }
     }
     for (RtContext* c : m->ctx) {

@@ -66,6 +66,8 @@ struct DTri {
 struct DTriN {
     float n[9];
 };
+/* the kernels address these arrays with shifted 32-bit byte offsets (rt_kernels.h: cur << 6, triIndex * 48u) */
+static_assert(sizeof(DPair) == 64 && sizeof(DTri) == 48 && sizeof(DTriN) == 36, "rt_kernels.h hard-codes the record sizes");
 struct DModel {
     float w2l[12]; /* row r: m[r], m[4+r], m[8+r], m[12+r] of worldToLocal */
     float l2w[12];

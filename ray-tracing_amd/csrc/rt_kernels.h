@@ -532,7 +532,7 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
 {
 #ifdef RT_LDS_NODE_FETCH
     /* 4 KB slab after [stack][pixel fields][mask extension]; wave-uniform address */
-    uint32_t* const nodeSlab = (extBase - (threadIdx.x & 63)) + (a.extWords ? 1 + a.extWords : 0) * RT_WAVE;
+    uint32_t* const nodeSlab = (extBase - (threadIdx.x & 63)) + (a.extWords ? 2 + a.extWords : 0) * RT_WAVE;
 #endif
     const DModel* __restrict__ models = a.models;
     const DPair* __restrict__ pairs = a.pairs;
@@ -1062,7 +1062,9 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     rdir = rt_normalize(jfp - rayOrigin);
                     transmittance = rt_v3s(1.0f);
                     pathLight = rt_v3s(0.0f);
-                    bounce = 0;
+                    if (MANY) extBase[(1 + a.extWords) * RT_WAVE] = 0u; /* this variant keeps the bounce count in LDS (a row behind the mask extension): at its
+                                                                          * register budget the compiler spilled it to scratch instead */
+                    else bounce = 0;
                     PXU(PX_SAMPLE) = grouped ? (PXU(PX_SAMPLE) & 0xffff0000u) | (uint32_t)(sample + 1) : (uint32_t)(sample + 1);
                     if (c.maxBounce >= 0) pathActive = true;                /* RC:485: the loop runs for i = 0 */
                     else { PXF(PX_TIX) = PXF(PX_TIX) + 0.0f; PXF(PX_TIY) = PXF(PX_TIY) + 0.0f; PXF(PX_TIZ) = PXF(PX_TIZ) + 0.0f; } /* Trace returned 0 (RC:578) */
@@ -1140,8 +1142,14 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     endPath = true;
                 } else {
                     transmittance = transmittance * rt_rcp(p);
-                    bounce++;
-                    if (bounce > a.maxBounce) endPath = true; /* RC:485: i <= MaxBounceCount */
+                    if (MANY) {
+                        const uint32_t b = extBase[(1 + a.extWords) * RT_WAVE] + 1u;
+                        extBase[(1 + a.extWords) * RT_WAVE] = b;
+                        if ((int)b > a.maxBounce) endPath = true;
+                    } else {
+                        bounce++;
+                        if (bounce > a.maxBounce) endPath = true; /* RC:485: i <= MaxBounceCount */
+                    }
                 }
             }
             if (endPath) {

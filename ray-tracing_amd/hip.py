@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "rt_create_multi", "rt_destroy_multi", "rt_multi_count", "rt_multi_context", "rt_multi_resize", "rt_multi_upload_scene",
     "rt_multi_update_models", "rt_multi_update_spheres", "rt_multi_set_params", "rt_multi_reset_accumulation",
     "rt_multi_render_frame", "rt_multi_render_frames", "rt_multi_synchronize", "rt_gather_accumulated", "rt_gather_frame",
-    "rt_multi_get_counters", "rt_multi_last_gather_ms", "rt_gather_accumulated_to_device", "rt_gather_frame_to_device",
+    "rt_multi_get_counters", "rt_multi_last_gather_ms", "rt_multi_peer_access", "rt_gather_accumulated_to_device", "rt_gather_frame_to_device",
 ]
 
 
@@ -69,6 +69,7 @@ class HipApi(abi.CApi):
         "gather_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
         "multi_get_counters": (C.c_int, [C.c_void_p, C.POINTER(abi.RtCounters)]),
         "multi_last_gather_ms": (C.c_double, [C.c_void_p]),
+        "multi_peer_access": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "gather_accumulated_to_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
         "gather_frame_to_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     }

@@ -11,7 +11,9 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_bench_n1*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r03_bench_n1*.json")))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_bench_n1*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r03_bench_n1*.json"))
+               + glob.glob(os.path.join(ROOT, "profiles", "r04_bench_n1*.json")))
+R04 = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_bench_n1*.json")))
 MULTI = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_bench_n[28]_*.json")))
 
 
@@ -32,7 +34,7 @@ def test_required_fields(path):
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
-        if key == "cpu_baseline" and "_config" in os.path.basename(path) and "r03" in os.path.basename(path):
+        if key == "cpu_baseline" and "_config" in os.path.basename(path) and ("r03" in os.path.basename(path) or "r04" in os.path.basename(path)):
             continue   # the round-3 lines of the other configs were taken with --no-cpu-baseline (the headline line has it)
         assert key in d, key
         assert isinstance(d[key], typ), (key, type(d[key]))
@@ -70,7 +72,7 @@ def test_roofline_object(path):
 def test_cpu_baseline_and_parity_objects(path):
     d = load(path)
     if "cpu_baseline" not in d:
-        assert "_config" in os.path.basename(path) and "r03" in os.path.basename(path)
+        assert "_config" in os.path.basename(path) and ("r03" in os.path.basename(path) or "r04" in os.path.basename(path))
         assert d["parity"]["bit_identical"] is True
         return
     c = d["cpu_baseline"]
@@ -80,6 +82,33 @@ def test_cpu_baseline_and_parity_objects(path):
     assert "pinned" in c["sample"]
     p = d["parity"]
     assert p["bit_identical"] is True and p["max_rel_err"] == 0.0 and "oracle" in p["checked_in_this_run"]
+
+
+def test_round4_lines_exist():
+    assert os.path.join(ROOT, "profiles", "r04_bench_n1.json") in R04 and os.path.join(ROOT, "profiles", "r04_bench_n1_k20.json") in R04
+
+
+@pytest.mark.parametrize("path", R04, ids=[os.path.basename(p) for p in R04])
+def test_round4_roofline_is_self_consistent(path):
+    """"saturated" is a number in the line (peak_at_mix from hardware-counted instruction types x the kernel's
+    static class make-up), the algorithmic-bytes figure that exceeds the memory system is marked void, FETCH_SIZE's factor is
+    the calibrated one, and a run with diagnostics carries no value."""
+    d = load(path)
+    assert d["diagnostics"] == [] and d["value"] is not None
+    r = d["roofline"]
+    for key in ("peak_at_mix", "cycles_per_valu_inst_at_mix", "valu_busy_at_mix", "frac_at_mix", "valu_type_shares", "peak_at_mix_derivation"):
+        assert key in r, key
+    assert 2.0 <= r["cycles_per_valu_inst_at_mix"] <= 8.2
+    assert math.isclose(r["peak_at_mix"], 1024 * 2.4e9 / r["cycles_per_valu_inst_at_mix"] / 1e9, rel_tol=1e-6)
+    assert r["peak_at_mix"] < r["peak"]                                 # the 2-cycle rate holds for fp32 add / mul / fma on VGPRs only
+    assert math.isclose(r["valu_busy_at_mix"], r["achieved"] / r["peak_at_mix"], rel_tol=1e-6)
+    assert math.isclose(r["frac_at_mix"], r["valu_busy_at_mix"] * r["lane_util"], rel_tol=1e-6)
+    assert 0.5 < r["valu_busy_at_mix"] < 1.15                           # a model: a few per cent above 1 is its error bar, not a measurement
+    assert math.isclose(sum(r["valu_type_shares"].values()), 1.0, rel_tol=1e-6)
+    sec = r["secondary_hbm_algorithmic"]
+    assert sec["void"] is (sec["frac_of_peak"] > 1.0) and math.isclose(sec["frac_of_peak"], sec["GBps"] / 8000.0, rel_tol=1e-9)
+    assert r["fetch_size_factor"]["factor"] == 2.0 and "r04_fetch_size_calibration" in r["fetch_size_factor"]["calibration"]
+    assert os.path.exists(os.path.join(ROOT, "profiles", "r04_fetch_size_calibration.txt")) and os.path.exists(os.path.join(ROOT, "profiles", "isa_mix.json"))
 
 
 @pytest.mark.parametrize("path", MULTI, ids=[os.path.basename(p) for p in MULTI])

@@ -45,8 +45,13 @@ def test_partitioned_contexts_bound_targets_and_gather_on_the_gpu(world, cfg):
     assert "DIST_GPU_OK" in p.stdout
 
 
-def _bench(world, *extra):
-    env = dict(os.environ, RT_BENCH_ONE_DEVICE="1", RT_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _bench(world, *extra, one_device=True):
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if one_device:
+        env.update(RT_BENCH_ONE_DEVICE="1", RT_BENCH_BACKEND="gloo")
+    else:
+        env.pop("RT_BENCH_ONE_DEVICE", None)
+        env.pop("RT_BENCH_BACKEND", None)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--no-cpu-baseline", "--no-pmc", *extra],
@@ -57,14 +62,14 @@ def _bench(world, *extra):
     return json.loads(lines[0])
 
 
-def _check_multi_rank_line(d, world, steps, resolution):
+def _check_multi_rank_line(d, world, steps, resolution, distinct=1):
     assert d["n_gpus"] == world and d["steps"] == steps and d["resolution"] == resolution
     assert d["value"] > 0 and d["gather_ms"] is not None and d["gather_error"] is None
     # every rank took part and said which device it ran on (one shared device here: the test hook)
     assert d["ranks_seen"] == world
     assert sorted(r["rank"] for r in d["devices_seen"]) == list(range(world))
     assert len({r["pid"] for r in d["devices_seen"]}) == world
-    assert d["distinct_devices"] == 1
+    assert d["distinct_devices"] == distinct
     # the gathered image holds every frame of every rank's strips ...
     assert d["gathered_image_complete"] is True, d["gathered_image"]
     assert d["gathered_image"]["alpha_min"] == d["gathered_image"]["alpha_max"] == d["gathered_image"]["alpha_expected"]
@@ -90,3 +95,38 @@ def test_bench_eight_ranks_on_the_north_star_workload():
     row-tiled over 8 ranks), reduced to 2 steps, the 8 ranks sharing this box's GPU."""
     d = _bench(8, "--config", "5", "--steps", "2", "--warmup", "1", "--no-batched")
     _check_multi_rank_line(d, 8, 2, [3840, 2160])
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two physical GPUs: the RCCL (backend nccl) gather between distinct devices")
+def test_bench_two_gpus_over_rccl():
+    """The path the driver's SCALE run takes, on real hardware when the box has it: one rank per GPU, backend "nccl" (= RCCL over
+    xGMI), the gather between DISTINCT devices; gathered image == the oracle's, two distinct devices reported."""
+    d = _bench(2, "--steps", "3", "--warmup", "1", one_device=False)
+    _check_multi_rank_line(d, 2, 3, [1920, 1080], distinct=2)
+    assert all(r["backend"] == "nccl" for r in d["devices_seen"])
+
+
+@pytest.mark.gpu
+def test_multi_context_peer_access_is_reported(pkg, api):
+    """rt_create_multi checks / enables peer access between its distinct devices and says how device-to-device copies travel."""
+    import ctypes as C
+    n = _gpu_count()
+    ids = (C.c_int * 2)(0, 1 if n >= 2 else 0)
+    m = C.c_void_p()
+    assert api.create_multi(ids, 2, C.byref(m)) == 0
+    pairs, enabled = C.c_int(-1), C.c_int(-1)
+    rc = api.multi_peer_access(m, C.byref(pairs), C.byref(enabled))
+    if n >= 2:
+        assert pairs.value == 2 and rc in (0, 1, 2) and 0 <= enabled.value <= 2
+    else:
+        assert rc == -1 and pairs.value == 0 and enabled.value == 0  # the same device twice: nothing to copy between devices
+    api.destroy_multi(m)

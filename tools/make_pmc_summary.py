@@ -20,5 +20,9 @@ for arg in sys.argv[1:]:
         "kernel_avg_us_rocprof": [k["avg_us"] for k in s["kernel_stats"] if "rt_trace_kernel<false" in k["name"]][0],
         "source": d,
     }
+    if "SQ_INSTS_VALU_TRANS_F32" in p and "SQ_INSTS_VALU_CVT" in p:  # tools/prof.sh's instruction-type passes (bench.py peak_at_mix)
+        out[key]["valu_types"] = {"arith": p["SQ_INSTS_VALU_ADD_F32"]["avg"] + p["SQ_INSTS_VALU_MUL_F32"]["avg"] + p["SQ_INSTS_VALU_FMA_F32"]["avg"],
+                                  "trans": p["SQ_INSTS_VALU_TRANS_F32"]["avg"], "int32": p["SQ_INSTS_VALU_INT32"]["avg"],
+                                  "int64": p["SQ_INSTS_VALU_INT64"]["avg"], "cvt": p["SQ_INSTS_VALU_CVT"]["avg"]}
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))
