@@ -167,6 +167,7 @@ namespace RayTraceHost
         [DllImport(Lib)] public static extern int rt_gather_accumulated_to_device(IntPtr multi, int root, IntPtr d_rgba, UIntPtr bytes);
         [DllImport(Lib)] public static extern int rt_gather_frame_to_device(IntPtr multi, int root, IntPtr d_rgba, UIntPtr bytes);
         [DllImport(Lib)] public static extern void rt_build_bvh_gpu_release();
+        [DllImport(Lib)] public static extern int rt_build_bvh_gpu_batch(int device_id, int n_meshes, IntPtr[] verts, IntPtr[] normals, int[] n_verts, IntPtr[] indices, int[] n_indices, int quality, IntPtr out_nodes, int[] out_n_nodes, int[] out_node_offset, IntPtr out_tris, int[] out_tri_offset, IntPtr out_stats);
 
         public static void Check(IntPtr ctx, int status)
         {

@@ -344,6 +344,14 @@ int rt_build_bvh_gpu(int device_id, const float* verts, const float* normals, in
                      const int32_t* indices, int n_indices, int quality,
                      RtBVHNode* out_nodes, int* out_n_nodes,
                      RtTriangle* out_tris, RtBvhStats* out_stats);
+/* The meshes of a scene in one call (what CreateAllMeshData does mesh by mesh, RCM:206-236): mesh k is built like rt_build_bvh_gpu
+ * would build it and its nodes / triangles are written directly behind mesh k-1's — out_nodes (capacity: the sum of 2 * max(1,
+ * triangles) over the meshes) and out_tris (the sum of the triangle counts) come out as the concatenated arrays the dispatcher uploads;
+ * out_node_offset[k] / out_tri_offset[k] are mesh k's nodeOffset / triOffset (RC:79-80), out_n_nodes[k] its node count. */
+int rt_build_bvh_gpu_batch(int device_id, int n_meshes, const float* const* verts, const float* const* normals, const int* n_verts,
+                           const int32_t* const* indices, const int* n_indices, int quality,
+                           RtBVHNode* out_nodes, int* out_n_nodes, int* out_node_offset,
+                           RtTriangle* out_tris, int* out_tri_offset, RtBvhStats* out_stats);
 /* rt_build_bvh_gpu keeps its device scratch between calls (a scene build calls it once per mesh; at most 4 GiB is kept,
  * larger builds free it on return).  The scratch is ONE pool for the process: builds from several threads are serialised on
  * it, and this call frees it whichever thread built last. */

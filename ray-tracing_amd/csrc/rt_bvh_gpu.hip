@@ -824,6 +824,31 @@ extern "C" void rt_build_bvh_gpu_release(void)
     gbvh::pool_release();
 }
 
+/* The meshes of a scene in one call (CreateAllMeshData, RCM:206-236): mesh k's nodes and triangles are written behind mesh
+ * k-1's, i.e. the arrays come out concatenated the way the dispatcher uploads them (offsets returned per mesh). */
+extern "C" int rt_build_bvh_gpu_batch(int device_id, int n_meshes, const float* const* verts, const float* const* normals, const int* n_verts,
+                                      const int32_t* const* indices, const int* n_indices, int quality, RtBVHNode* out_nodes, int* out_n_nodes,
+                                      int* out_node_offset, RtTriangle* out_tris, int* out_tri_offset, RtBvhStats* out_stats)
+{
+    if (n_meshes < 0 || (n_meshes > 0 && (!verts || !normals || !n_verts || !indices || !n_indices || !out_nodes || !out_n_nodes || !out_node_offset ||
+                                          !out_tris || !out_tri_offset)))
+        return RT_ERR_INVALID_ARG;
+    long long nodeOff = 0, triOff = 0;
+    for (int k = 0; k < n_meshes; k++) {
+        if (n_indices[k] < 0 || n_indices[k] % 3) return RT_ERR_INVALID_ARG;
+        out_node_offset[k] = (int)nodeOff;
+        out_tri_offset[k] = (int)triOff;
+        out_n_nodes[k] = 0;
+        const int rc = gbvh::build(device_id, verts[k], normals[k], n_verts[k], indices[k], n_indices[k], quality, out_nodes + nodeOff, &out_n_nodes[k],
+                                   out_tris + triOff, out_stats ? &out_stats[k] : nullptr);
+        if (rc != RT_OK) return rc;
+        nodeOff += out_n_nodes[k];
+        triOff += n_indices[k] / 3;
+        if (nodeOff > 0x7fffffffLL || triOff > 0x7fffffffLL) return RT_ERR_SCENE;
+    }
+    return RT_OK;
+}
+
 extern "C" int rt_build_bvh_gpu(int device_id, const float* verts, const float* normals, int n_verts, const int32_t* indices, int n_indices,
                                 int quality, RtBVHNode* out_nodes, int* out_n_nodes, RtTriangle* out_tris, RtBvhStats* out_stats)
 {

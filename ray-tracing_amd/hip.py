@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "rt_synchronize", "rt_get_frame", "rt_read_frame", "rt_read_accumulated", "rt_display", "rt_display_srgb8",
     "rt_write_accumulated", "rt_timer_begin", "rt_timer_end",
     "rt_enable_stats", "rt_reset_counters", "rt_get_counters", "rt_build_bvh", "rt_build_bvh_mt", "rt_build_bvh_gpu", "rt_build_bvh_gpu_release", "rt_camera_view_params", "rt_version",
-    "rt_debug_intersect", "rt_debug_math_eval", "rt_debug_phase_profile",
+    "rt_debug_intersect", "rt_debug_math_eval", "rt_debug_phase_profile", "rt_build_bvh_gpu_batch",
     "rt_flush",
     "rt_create_multi", "rt_destroy_multi", "rt_multi_count", "rt_multi_context", "rt_multi_resize", "rt_multi_upload_scene",
     "rt_multi_update_models", "rt_multi_update_spheres", "rt_multi_set_params", "rt_multi_reset_accumulation",
@@ -49,6 +49,8 @@ class HipApi(abi.CApi):
         "build_bvh_gpu": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                     C.POINTER(C.c_int), C.c_void_p, C.POINTER(abi.RtBvhStats)]),
         "build_bvh_gpu_release": (None, []),
+        "build_bvh_gpu_batch": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
         "debug_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
         "debug_math_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
         "debug_phase_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -114,6 +116,27 @@ class HipApi(abi.CApi):
         if rc != abi.RT_OK:
             raise abi.RtError(rc, "build_bvh_gpu failed")
         return nodes[: n_nodes.value].copy(), tris, stats.as_dict()
+
+    def build_bvh_arrays_gpu_batch(self, meshes, quality=abi.BVH_QUALITY_HIGH, device_id=0):
+        """rt_build_bvh_gpu_batch: [(verts, normals, indices), ...] -> (nodes, triangles, [(nodeOffset, triOffset, stats)]) — the
+        concatenated arrays of CreateAllMeshData, written in place by the library (no per-mesh copies on this side)."""
+        n = len(meshes)
+        vs = [np.ascontiguousarray(m[0], dtype=np.float32).reshape(-1, 3) for m in meshes]
+        ns = [np.ascontiguousarray(m[1], dtype=np.float32).reshape(-1, 3) for m in meshes]
+        ix = [np.ascontiguousarray(m[2], dtype=np.int32).reshape(-1) for m in meshes]
+        ntri = [len(i) // 3 for i in ix]
+        nodes = np.empty(sum(2 * max(1, t) for t in ntri), dtype=abi.node_dtype)
+        tris = np.empty(sum(ntri), dtype=abi.triangle_dtype)
+        ptrs = lambda arrs: (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        ints = lambda vals: (C.c_int * n)(*vals)
+        n_nodes, node_off, tri_off = ints([0] * n), ints([0] * n), ints([0] * n)
+        stats = (abi.RtBvhStats * n)()
+        rc = self.build_bvh_gpu_batch(int(device_id), n, ptrs(vs), ptrs(ns), ints([len(v) for v in vs]), ptrs(ix), ints([len(i) for i in ix]),
+                                      int(quality), nodes.ctypes.data, n_nodes, node_off, tris.ctypes.data, tri_off, stats)
+        if rc != abi.RT_OK:
+            raise abi.RtError(rc, "build_bvh_gpu_batch failed")
+        total = (node_off[n - 1] + n_nodes[n - 1]) if n else 0
+        return nodes[:total], tris, [(node_off[k], tri_off[k], stats[k].as_dict()) for k in range(n)]
 
     def create_tracer(self, device_id=0):
         h = C.c_void_p()

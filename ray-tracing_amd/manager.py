@@ -263,6 +263,22 @@ class RayComputeManager:
         n_tris = n_nodes = 0
         meshLookup = {}
         meshInfo = np.zeros(len(models), dtype=abi.model_dtype)
+        if getattr(self, "bvhOnGpu", False) and hasattr(self.api, "build_bvh_arrays_gpu_batch") and len(models):
+            # every distinct mesh in ONE call: the library writes the concatenated arrays itself (rt_build_bvh_gpu_batch)
+            uniq = []
+            for model in models:
+                if id(model.Mesh) not in meshLookup:
+                    meshLookup[id(model.Mesh)] = len(uniq)
+                    uniq.append(model.Mesh)
+            nd, tr, per = self.api.build_bvh_arrays_gpu_batch([(m.vertices, m.normals, m.triangles) for m in uniq], self.bvhQuality)
+            for m, (_, _, stats) in zip(uniq, per):
+                self.bvhStats[m.name] = stats
+            for i, model in enumerate(models):
+                meshInfo[i]["nodeOffset"], meshInfo[i]["triOffset"] = per[meshLookup[id(model.Mesh)]][:2]
+                meshInfo[i]["worldToLocal"] = matrix_to_abi(model.transform.worldToLocalMatrix)
+                meshInfo[i]["localToWorld"] = matrix_to_abi(model.transform.localToWorldMatrix)
+                meshInfo[i]["material"] = model.material.pack()
+            return {"meshInfo": meshInfo, "triangles": tr, "nodes": nd}
         for i, model in enumerate(models):
             key = id(model.Mesh)
             if key not in meshLookup:

@@ -210,3 +210,41 @@ def test_gpu_builder_leaves_the_callers_device_state_alone(pkg, api):
     rc = api.build_bvh_gpu(0, mesh.vertices.ctypes.data, mesh.normals.ctypes.data, len(mesh.vertices), bad.ctypes.data, len(bad), 1,
                            nodes.ctypes.data, C.byref(nn), tris.ctypes.data, None)
     assert rc == pkg.abi.RT_ERR_INVALID_ARG and nn.value == 0
+
+
+@pytest.mark.gpu
+def test_gpu_batch_builder_writes_the_concatenated_arrays(pkg, api):
+    """rt_build_bvh_gpu_batch: the meshes of a scene in one call; nodes and triangles come out concatenated exactly as
+    CreateAllMeshData (RCM:206-236) concatenates per-mesh host builds, with each mesh's nodeOffset / triOffset; builds from
+    several threads share the one scratch pool and still give the same bytes."""
+    import threading
+    meshes = [pkg.meshes.cube(), pkg.meshes.icosphere(4, 1.0, 7), pkg.meshes.quad(), pkg.meshes.rounded_cube(8), pkg.meshes.icosphere(5, 1.0, 2)]
+    for quality in (0, 1, 2):
+        nd, tr, per = api.build_bvh_arrays_gpu_batch([(m.vertices, m.normals, m.triangles) for m in meshes], quality)
+        no = to = 0
+        for m, (noff, toff, stats) in zip(meshes, per):
+            n1, t1, s1 = api.build_bvh_arrays(m.vertices, m.normals, m.triangles, quality)
+            assert (noff, toff) == (no, to)
+            assert nd[no:no + len(n1)].tobytes() == n1.tobytes() and tr[to:to + len(t1)].tobytes() == t1.tobytes(), (m.name, quality)
+            s1.pop("timeMs"), stats.pop("timeMs")
+            assert s1 == stats
+            no, to = no + len(n1), to + len(t1)
+        assert len(nd) == no and len(tr) == to
+    # an empty batch is fine; a bad mesh in the middle reports its error
+    nd, tr, per = api.build_bvh_arrays_gpu_batch([], 1)
+    assert len(nd) == 0 and len(tr) == 0 and per == []
+    bad = meshes[1].triangles.copy()
+    bad[4] = 10**6
+    with pytest.raises(pkg.abi.RtError):
+        api.build_bvh_arrays_gpu_batch([(meshes[0].vertices, meshes[0].normals, meshes[0].triangles), (meshes[1].vertices, meshes[1].normals, bad)], 1)
+    # concurrent builds from short-lived threads: serialised on the process-wide pool, same bytes, nothing left per thread
+    ref = api.build_bvh_arrays(meshes[4].vertices, meshes[4].normals, meshes[4].triangles, 1)
+    out = [None] * 6
+    def work(k):
+        out[k] = api.build_bvh_arrays_gpu(meshes[4].vertices, meshes[4].normals, meshes[4].triangles, 1)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for o in out:
+        assert o[0].tobytes() == ref[0].tobytes() and o[1].tobytes() == ref[1].tobytes()
+    api.build_bvh_gpu_release()
