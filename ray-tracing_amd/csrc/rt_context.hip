@@ -90,7 +90,15 @@ struct RtContext {
     unsigned long long* dTileQueue = nullptr;      /* monotonic tile counters of the persistent kernel, one per render stream */
     unsigned long long tileQueueNext[2] = {0, 0};  /* value each counter will have when that stream's next launch starts */
     uint32_t* dTileCost = nullptr;  /* per tile: longest pixel chain (segments per frame) seen so far */
-    uint32_t* dTileOrder = nullptr; /* queue position -> tile, longest chain first */
+    /* queue position -> tile, longest chain first.  Two buffers: a re-sort writes the one no running kernel reads (the kernels in
+     * flight keep the order they were launched with), so it does not have to join the streams */
+    uint32_t* dTileOrder[2] = {nullptr, nullptr};
+    uint32_t* dTileKey = nullptr;   /* the sort's snapshot of the costs (kernels in flight keep raising them) */
+    int orderCur = 0;
+    hipEvent_t evSort = nullptr;    /* after the last sort; sortPending[s]: stream s has not been ordered after it yet */
+    bool sortPending[2] = {false, false};
+    hipEvent_t evOrderRetire[2] = {nullptr, nullptr}; /* recorded on the OTHER stream when the order buffer went out of use: its next rewrite waits for it */
+    bool retireValid[2] = {false, false};
     int orderTiles = 0;             /* tiles the two arrays are sized for; 0 = none */
     bool orderValid = false;
     long long framesSinceResize = 0;
@@ -305,6 +313,9 @@ int rt_create(int device_id, RtContext** out)
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evAccWriter[0], hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evAccWriter[1], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evSort, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evOrderRetire[0], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evOrderRetire[1], hipEventDisableTiming));
         return RT_OK;
     };
     if (int rc = init()) { /* the message stays readable through rt_last_error(NULL) */
@@ -356,7 +367,11 @@ void rt_destroy(RtContext* ctx)
     hipFree(ctx->dCounters);
     hipFree(ctx->dTileQueue);
     hipFree(ctx->dTileCost);
-    hipFree(ctx->dTileOrder);
+    hipFree(ctx->dTileOrder[0]);
+    hipFree(ctx->dTileOrder[1]);
+    hipFree(ctx->dTileKey);
+    if (ctx->evSort) hipEventDestroy(ctx->evSort);
+    for (int i = 0; i < 2; i++) if (ctx->evOrderRetire[i]) hipEventDestroy(ctx->evOrderRetire[i]);
     hipFree(ctx->dDisplay);
     hipFree(ctx->dStaging[0]);
     hipFree(ctx->dStaging[1]);
@@ -1307,32 +1322,70 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         }
 #endif
     }
+    /* Fused launches alternate between the context's two streams (own streams only), each with its own staging slab: the
+     * trace kernel of launch k+1 — other frames, nothing shared but the scene — starts while launch k drains (a launch ends
+     * with waves retiring one by one for as long as one pixel chain lasts), and only the rt_accumulate_kernels, which add
+     * into the accumulation buffer in FRAME order, are chained by events. */
+    const bool staged = nFrames > 1;
+    const size_t nPix = (size_t)ctx->localRows * ctx->W;
+    const bool twoOwn = ctx->twoStreams && ctx->stream == ctx->ownStream && ctx->sideStream;
+    const int lane = (staged && twoOwn && ctx->alternate) ? ctx->stagedNext : 0;
+    hipStream_t laneStream = lane ? ctx->sideStream : ctx->stream;
     /* longest-chain-first queue order, learnt from the frames already rendered at this size */
     if (ctx->lptEnabled && ctx->orderTiles != tiles) {
+        HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
         hipFree(ctx->dTileCost); ctx->dTileCost = nullptr;
-        hipFree(ctx->dTileOrder); ctx->dTileOrder = nullptr;
+        hipFree(ctx->dTileOrder[0]); hipFree(ctx->dTileOrder[1]); ctx->dTileOrder[0] = ctx->dTileOrder[1] = nullptr;
+        hipFree(ctx->dTileKey); ctx->dTileKey = nullptr;
         HIP_TRY(ctx, hipMalloc(&ctx->dTileCost, sizeof(uint32_t) * tiles));
-        HIP_TRY(ctx, hipMalloc(&ctx->dTileOrder, sizeof(uint32_t) * tiles));
+        HIP_TRY(ctx, hipMalloc(&ctx->dTileOrder[0], sizeof(uint32_t) * tiles));
+        HIP_TRY(ctx, hipMalloc(&ctx->dTileOrder[1], sizeof(uint32_t) * tiles));
+        HIP_TRY(ctx, hipMalloc(&ctx->dTileKey, sizeof(uint32_t) * tiles));
         HIP_TRY(ctx, hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * tiles, joined(ctx)));
         ctx->orderTiles = tiles;
         ctx->orderValid = false;
+        ctx->orderCur = 0;
+        ctx->sortPending[0] = ctx->sortPending[1] = false;
+        ctx->retireValid[0] = ctx->retireValid[1] = false;
         ctx->framesSinceResize = 0;
         ctx->nextSortAt = 1;
     }
     if (ctx->lptEnabled) {
         const long long f = ctx->framesSinceResize;
-        /* re-sort once 1, 2, 4, 8, ... frames have been recorded.  The sort rewrites the order array the running kernels read,
-         * so it joins the two streams — and a join in the middle of back-to-back launches serialises the next launch behind the
-         * drain of the previous one (the driver's K = 20 run: 1 + 16 + 3 frames, the sort due at the 3-frame tail).  While the
-         * GPU is busy the sort therefore waits for the next launch that finds it idle, unless it is overdue by a factor of 4. */
-        if (f >= ctx->nextSortAt && (f >= 4 * ctx->nextSortAt || f < 8 || gpu_idle(ctx))) {
+        /* Re-sort once 1, 2, 4, 8, ... frames have been recorded.  Round 4: the sort no longer joins the two streams (a join in the
+         * middle of back-to-back launches serialises the next launch behind the drain of the previous one: the driver's K = 20 run,
+         * 1 + 16 + 3 frames with the sort due at the 3-frame tail).  It runs on the stream of the launch that first uses it, writes
+         * the order buffer that no running kernel reads, works on its own snapshot of the costs (running kernels keep raising them),
+         * and the other stream is ordered after it by an event before its next launch. */
+        if (f >= ctx->nextSortAt) {
             while (ctx->nextSortAt <= f) ctx->nextSortAt *= 2;
-            hipLaunchKernelGGL(rtk::rt_order_kernel, dim3(1), dim3(1024), 0, joined(ctx), ctx->dTileCost, ctx->dTileOrder, tiles);
+            const int target = ctx->orderValid ? 1 - ctx->orderCur : 0;
+            const int ss = lane; /* a single frame's two halves: sorted on the main stream, the side stream waits */
+            hipStream_t S = ss ? ctx->sideStream : ctx->stream;
+            if (ss == 1 && ctx->needFork) {
+                HIP_TRY(ctx, hipEventRecord(ctx->evFork, ctx->stream));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->sideStream, ctx->evFork, 0));
+                ctx->needFork = false;
+            }
+            if (ctx->retireValid[target]) HIP_TRY(ctx, hipStreamWaitEvent(S, ctx->evOrderRetire[target], 0)); /* its last readers on the other stream */
+            hipLaunchKernelGGL(rtk::rt_order_kernel, dim3(1), dim3(1024), 0, S, ctx->dTileCost, ctx->dTileKey, ctx->dTileOrder[target], tiles);
             HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipEventRecord(ctx->evSort, S));
+            ctx->sortPending[ss] = false;
+            ctx->sortPending[1 - ss] = twoOwn;
+            if (ctx->orderValid && twoOwn) { /* the buffer going out of use: whatever the other stream holds so far may still read it */
+                HIP_TRY(ctx, hipEventRecord(ctx->evOrderRetire[ctx->orderCur], ss ? ctx->stream : ctx->sideStream));
+                ctx->retireValid[ctx->orderCur] = true;
+            }
+            if (ss == 1) ctx->sideDirty = true;
+            ctx->orderCur = target;
             ctx->orderValid = true;
+            /* a new order moves pixels between the two halves of a two-part frame: the next such frame's halves must come after
+             * BOTH streams' last kernels that add into the accumulation buffer */
+            ctx->accWriterFull[0] = ctx->accWriterFull[1] = true;
         }
         a.tileCost = ctx->dTileCost;
-        a.tileOrder = ctx->orderValid ? ctx->dTileOrder : nullptr;
+        a.tileOrder = ctx->orderValid ? ctx->dTileOrder[ctx->orderCur] : nullptr;
         ctx->framesSinceResize += nFrames;
     }
     /* Persistent launches.  Queue position q of part p is entry q*parts + p of the (longest chain
@@ -1347,15 +1400,6 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
      * frees, and the two streams settle into taking turns.  With a caller-provided stream the
      * caller's stream order is the contract, so there is one kernel on that stream. */
     /* several frames in one launch: (tile, frame) items, per-frame colours staged and summed in frame order afterwards */
-    const bool staged = nFrames > 1;
-    const size_t nPix = (size_t)ctx->localRows * ctx->W;
-    /* Fused launches alternate between the context's two streams (own streams only), each with its own staging slab: the
-     * trace kernel of launch k+1 — other frames, nothing shared but the scene — starts while launch k drains (a launch ends
-     * with waves retiring one by one for as long as one pixel chain lasts), and only the rt_accumulate_kernels, which add
-     * into the accumulation buffer in FRAME order, are chained by events. */
-    const bool twoOwn = ctx->twoStreams && ctx->stream == ctx->ownStream && ctx->sideStream;
-    const int lane = (staged && twoOwn && ctx->alternate) ? ctx->stagedNext : 0;
-    hipStream_t laneStream = lane ? ctx->sideStream : ctx->stream;
     if (staged) {
         const size_t need = (size_t)nFrames * nPix * 16;
         if (!ctx->stagingUnavailable && ctx->stagingBytes[lane] < need) {
@@ -1495,6 +1539,10 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
 #endif
         a.tileQueue = ctx->dTileQueue + q;
         a.tileQueueBase = ctx->tileQueueNext[q] - (a.queueStart ? 0ull : (unsigned long long)grid);
+        if (ctx->sortPending[q]) { /* the order array this kernel reads was sorted on the other stream */
+            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->evSort, 0));
+            ctx->sortPending[q] = false;
+        }
         if (!staged) { /* the trace kernel itself adds into the accumulation buffer (RCC:20-23) */
             const int orc = order_acc_writer(q, parts == 1);
             if (orc) return orc;

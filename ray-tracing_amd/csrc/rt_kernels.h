@@ -1266,14 +1266,17 @@ __global__ void rt_debug_math_kernel(int op, const float* x, const float* y, flo
  * serial chain (quirk Q13), so a frame cannot end before its longest chain does; starting
  * the long ones first keeps the end of the frame full of short work.  Pure scheduling:
  * the image does not depend on it. */
-__global__ void __launch_bounds__(1024) rt_order_kernel(const uint32_t* cost, uint32_t* order, int nTiles)
+__global__ void __launch_bounds__(1024) rt_order_kernel(const uint32_t* cost, uint32_t* key, uint32_t* order, int nTiles)
 {
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t base[1024];
     const int t = threadIdx.x;
     hist[t] = 0;
+    /* the costs may still be raised by kernels in flight (atomicMax): both passes below must see the SAME keys, or the result
+     * is not a permutation — so the keys are snapshot first (one workgroup: its own global writes are visible after the barrier) */
+    for (int i = t; i < nTiles; i += 1024) key[i] = 1023u - (cost[i] < 1023u ? cost[i] : 1023u);
     __syncthreads();
-    for (int i = t; i < nTiles; i += 1024) atomicAdd(&hist[1023u - (cost[i] < 1023u ? cost[i] : 1023u)], 1u);
+    for (int i = t; i < nTiles; i += 1024) atomicAdd(&hist[key[i]], 1u);
     __syncthreads();
     if (t == 0) {
         uint32_t run = 0;
@@ -1281,10 +1284,7 @@ __global__ void __launch_bounds__(1024) rt_order_kernel(const uint32_t* cost, ui
     }
     __syncthreads();
     /* stable within a bucket is not needed; keep tile order roughly spatial by walking in index order per thread */
-    for (int i = t; i < nTiles; i += 1024) {
-        const uint32_t k = 1023u - (cost[i] < 1023u ? cost[i] : 1023u);
-        order[atomicAdd(&base[k], 1u)] = (uint32_t)i;
-    }
+    for (int i = t; i < nTiles; i += 1024) order[atomicAdd(&base[key[i]], 1u)] = (uint32_t)i;
 }
 
 /* Display pass — Display.shader:42-47: col = tex / Frame (the blit of RayTraceDisplay.cs:9-23).
