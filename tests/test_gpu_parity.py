@@ -530,6 +530,34 @@ def test_frame_group_size_does_not_change_a_bit(pkg, api, monkeypatch):
                 assert out[2] == ref[cfg][2]
 
 
+@pytest.mark.parametrize("alternate", ["0", "1"])
+def test_alternating_fused_launches_add_frames_in_frame_order(pkg, api, orc, alternate, monkeypatch):
+    """Round 4: consecutive fused launches run on the context's two streams in turn (own staging slab each), the re-sort of the tile
+    order runs without joining the streams, and only the accumulate kernels are chained.  A long burst of back-to-back
+    rt_render_frame calls (1 + 16 + 16 + 16 + ... frames, sorts due after 1, 2, 4, 8, 16, 32 frames), interleaved with single frames
+    from an idle GPU (two half kernels), must leave the oracle's accumulation buffer and last frame — the
+    fp32 sum is order-sensitive, so any frame added out of order or twice shows."""
+    monkeypatch.setenv("RT_ALTERNATE", alternate)
+    for cfg, (w, h) in ((2, (200, 120)), (3, (176, 96))):
+        imgs = []
+        for lib, tr in ((api, api.create_tracer(0)), (orc, orc.create_tracer(16))):
+            sc = pkg.scenes.get(cfg)
+            mgr = sc.make_manager(tr, lib, w, h)
+            mgr.OnEnable(renderSeed=21)
+            for burst in (37, 1, 5, 18):
+                for _ in range(burst):
+                    tr.render_frame()          # back to back: held back and fused by the library
+                if burst == 1 and hasattr(tr, "synchronize"):
+                    tr.synchronize()           # the next burst starts from an idle GPU
+            mgr.numAccumulatedFrames += 37 + 1 + 5 + 18
+            imgs.append((tr.read_accumulated().copy(), tr.read_frame().copy(), tr.frame()))
+            tr.close()
+        (a, fa, na), (b, fb, nb) = imgs
+        assert na == nb == 62
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (cfg, alternate, int(np.any(a.view(np.uint32) != b.view(np.uint32), axis=-1).sum()))
+        assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32)), (cfg, alternate)
+
+
 @pytest.mark.parametrize("coalesce", ["0", "1"])
 def test_held_back_frames_see_the_state_they_were_requested_with(pkg, api, orc, coalesce, monkeypatch):
     """rt_render_frame holds frames requested while the GPU is busy back and launches them fused.  Every call that
