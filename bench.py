@@ -133,6 +133,42 @@ def cpu_baseline(pkg, scene_id, width, height, min_s=10.0, max_frames=4, threads
     }
 
 
+def cpu_baseline_reference(pkg, scene_id, width, height, min_s=8.0, max_frames=2):
+    """The REFERENCE'S OWN loop on one pinned host core: oracle/_ref/libref.so is the reference's shader text (RayCommon.hlsl +
+    RayCompute.compute) compiled as C++ by oracle/make_ref.py in the container that has the reference checkout; it travels to the GPU box
+    as a prebuilt library.  Model-only scenes (the reference has no sphere buffer); None when the library is not there."""
+    ref = graft.load_ref()
+    if ref is None:
+        return None
+    orc = graft.load_oracle()  # BVH builder + camera helper of the manager mirror (BVH.cs is C#, not part of the shader text)
+    old = os.sched_getaffinity(0) if hasattr(os, "sched_setaffinity") else None
+    pinned = min(old) if old else None
+    if old:
+        os.sched_setaffinity(0, {pinned})
+    try:
+        tr = ref.create_tracer(threads=1)
+        sc = pkg.scenes.get(scene_id)
+        sc.spheres = []
+        mgr = sc.make_manager(tr, orc, width, height)
+        mgr.OnEnable(renderSeed=1)
+        tr.reset_counters()
+        t0 = time.perf_counter()
+        frames = 0
+        while frames < max_frames and (frames == 0 or time.perf_counter() - t0 < min_s):
+            mgr.RenderFrame()
+            frames += 1
+        dt = time.perf_counter() - t0
+        c = tr.counters()
+        tr.close()
+    finally:
+        if old:
+            os.sched_setaffinity(0, old)
+    return {"value": c["segments"] / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
+            "sample": f"oracle/_ref/libref.so (the reference's HLSL text compiled as C++, g++ -O2, strict fp32), 1 thread pinned to cpu {pinned}: "
+                      f"frames 1..{frames} of the same scene at {width}x{height} ({c['segments']} segments in {dt:.1f} s)",
+            "nproc": os.cpu_count()}
+
+
 def parity_check(pkg, api, dev_index, scene_id, width, height, strips):
     """In-run parity: frame 1 of the benchmarked scene at the benchmarked size on a fresh context, 8-row
     strips re-rendered by the oracle — bitwise comparison + per-channel relative L2 of the strips."""
@@ -674,6 +710,12 @@ def main():
                 r2["frames_per_launch"] = 16
                 r2["mrays_per_s_fused_launches"] = seg2 / (ms2 * 1e-3) / 1e6
                 r2["workload"] = f"{sc2.name}: {sc2.width}x{sc2.height}, {sc2.unique_triangles()} triangles, BASELINE.json configs[{cfg - 1}]"
+                if cfg == 3 and not args.no_cpu_baseline:
+                    # the reference's own loop (its shader text compiled as C++) on one host core, a bounded sample at 1/16 of the area
+                    cb = cpu_baseline_reference(pkg, cfg, sc2.width // 4, sc2.height // 4)
+                    if cb:
+                        r2["cpu_baseline"] = cb
+                        r2["gpu_over_cpu"] = r2["mrays_per_s_fused_launches"] / cb["value"]
                 sec[f"config{cfg}"] = r2
             out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
