@@ -159,3 +159,124 @@ if __name__ == "__main__":
             for rm in (4, 8, 16):
                 k = many(sim_queued, 24, R=R, refill_min=rm).report(f"queued stages R={R} refill_min={rm}")
                 print(f"       -> x{b / k:.2f}")
+
+
+def sim_lane_affine(pixels, tiles_per_wave, K=3, shade_min=48, cam_min=48, burst=3, swap_cost=25):
+    """The on-chip variant: every LANE owns K chains (registers / LDS of that lane; nothing moves between lanes).  One of a lane's chains
+    may be in traversal (it has the lane's LDS stack); the others wait at a segment boundary.  A lane whose traversing chain finishes
+    continues with another of ITS chains that is ready to traverse, if it has one.  Shade / camera batches run when at least
+    shade_min / cam_min lanes have a chain waiting for that stage (one chain per lane per batch), or when nothing can traverse."""
+    acc = Acc()
+    pool = list(pixels[: tiles_per_wave * 64])
+    ch = [[Chain() for _ in range(K)] for _ in range(64)]
+    trav = [None] * 64  # the chain of lane i that holds the stack
+
+    def begin(cs):
+        if not cs:
+            return
+        acc.run("BEGIN", len(cs))
+        for c in cs:
+            c.begin()
+            acc.segments += 1
+
+    def lanes_with(state_pred):
+        out = []
+        for i in range(64):
+            for c in ch[i]:
+                if c is not trav[i] and state_pred(c):
+                    out.append((i, c))
+                    break
+        return out
+
+    while True:
+        # lanes without a traversing chain pick up one of their ready ones (state T, not started)
+        sw = 0
+        for i in range(64):
+            if trav[i] is None or trav[i].state != "T":
+                trav[i] = None
+                for c in ch[i]:
+                    if c.state == "T":
+                        trav[i] = c
+                        sw += 1
+                        break
+        if sw:
+            acc.run("SWAP", sw, cost=swap_cost)
+        act = [c for c in trav if c is not None]
+        need_s = lanes_with(lambda c: c.state == "S")
+        need_c = lanes_with(lambda c: c.state in ("G", "D") and (c.state == "G" or pool))
+        if len(need_s) >= shade_min or (not act and need_s):
+            batch = [c for _, c in need_s]
+            shade_stage(batch, acc)
+            begin([c for c in batch if c.state == "I"])
+            continue
+        if len(need_c) >= cam_min or (not act and need_c):
+            batch = [c for _, c in need_c]
+            fin = 0
+            for c in batch:
+                if c.state == "G" and c.si >= len(c.px):
+                    c.raygen_or_finish()
+                    fin += 1
+            if fin:
+                acc.run("FINISH", fin)
+            n = 0
+            for c in batch:
+                if c.state == "D" and pool:
+                    c.assign(pool.pop(0))
+                    n += 1
+            if n:
+                acc.run("REFILL", n)
+            g = [c for c in batch if c.state == "G"]
+            if g:
+                acc.run("RAYGEN", len(g))
+                for c in g:
+                    c.raygen_or_finish()
+            begin([c for c in batch if c.state == "I"])
+            continue
+        if not act:
+            break
+        cnt = {"A": 0, "B": 0, "C": 0}
+        for c in act:
+            cnt[c.phase()] += 1
+        acc.run("VOTE", len(act))
+        if cnt["A"] >= cnt["B"] and cnt["A"] >= cnt["C"]:
+            served = [c for c in act if c.phase() == "A"]
+            acc.run("A", len(served))
+            for c in served:
+                c.step()
+        elif cnt["B"] >= cnt["C"]:
+            for _ in range(burst):
+                served = [c for c in act if c.state == "T" and c.phase() == "B"]
+                if not served:
+                    break
+                acc.run("B", len(served))
+                for c in served:
+                    c.step()
+        else:
+            served = [c for c in act if c.phase() == "C"]
+            rem = [c.toks[c.pos] for c in served]
+            for k in range(max(rem)):
+                acc.run("C", sum(1 for r in rem if r > k))
+            for c in served:
+                c.step()
+    return acc
+
+
+if __name__ == "__main__" and len(sys.argv) > 1:
+    for path in sys.argv[1:]:
+        pixels = parse(path)
+        ntile = len(pixels) // 64
+        def many2(fn, per, **kw):
+            tot = Acc()
+            for w in range(ntile // per):
+                a = fn(pixels[w * per * 64:(w + 1) * per * 64], per, **kw)
+                for d, s in ((tot.cost, a.cost), (tot.execs, a.execs), (tot.lanes, a.lanes)):
+                    for k, v in s.items():
+                        d[k] = d.get(k, 0) + v
+                tot.segments += a.segments
+            return tot
+        print(f"==== {path}: lane-affine on-chip variants")
+        b = many2(sim_base, 24).report("shipped schedule")
+        for K in (2, 3, 4):
+            for sm in (32, 48):
+                k = many2(sim_lane_affine, 24, K=K, shade_min=sm, cam_min=sm).report(f"lane-affine K={K} batch at {sm} lanes")
+                print(f"       -> x{b / k:.2f}")
