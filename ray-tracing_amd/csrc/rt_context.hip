@@ -20,7 +20,10 @@
 
 #include <chrono>
 
-#ifdef RT_QUEUED_EXPERIMENT /* make queued: the queued-stages form of the trace kernel, measured 3x slower */
+#ifdef RT_WG_EXPERIMENT /* make wg: the queued stages with the parked chains in a workgroup-wide LDS pool (rt_kernels_wg.h) */
+#define RT_QUEUED_EXPERIMENT
+#include "rt_kernels_wg.h"
+#elif defined(RT_QUEUED_EXPERIMENT) /* make queued: the queued-stages form of the trace kernel, measured 3x slower */
 #include "rt_kernels_q.h"
 #else
 #include "rt_kernels.h"
@@ -105,8 +108,8 @@ struct RtContext {
     long long nextSortAt = 1;
     bool lptEnabled = true;
     int numCUs = 256;
-    int occPerCU[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    size_t occBytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int occPerCU[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    size_t occBytes[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool verbose = false;
     /* rt_render_frame calls that arrive while earlier frames are still executing are held back (at most
      * RT_MAX_FUSED_FRAMES) and leave as ONE fused launch at the next call that needs them (flush_pending) */
@@ -114,9 +117,13 @@ struct RtContext {
     long long pxColdWaves = 0;
     /* queued-stages kernel form (rt_kernels_q.h): BVH scenes with up to 64 models */
     bool queued = false;        /* RT_QUEUED=1 */
+    bool wg = false;            /* RT_WG=1: the workgroup form (make wg) */
+    int wgTravWaves = 6;        /* RT_WG_NT */
     int qFlushMin = 16, qRefillMin = 16, qStarveMin = 32; /* RT_Q_FLUSH / RT_Q_REFILL / RT_Q_STARVE (scheduling only) */
     void* dQRecords = nullptr;  /* 2 launch slots x qWaves x RT_Q_WAVE_DWORDS dwords */
     long long qWaves = 0;
+    void* dWgRecords = nullptr; /* workgroup form: 2 launch slots x wgUnits x RT_WG_GLOBAL_DWORDS dwords of pixel records */
+    long long wgUnits = 0;
     int frameGroupOverride = 0; /* RT_FRAME_GROUP: frames per (tile, frame group) item of fused launches (tuning hook) */
     bool coalesce = true;  /* RT_COALESCE=0: every rt_render_frame launches at once */
     int pending = 0;       /* frames [frame - pending, frame) requested but not launched yet */
@@ -332,6 +339,8 @@ int rt_create(int device_id, RtContext** out)
     if (const char* fg = getenv("RT_FRAME_GROUP")) ctx->frameGroupOverride = atoi(fg);
     if (const char* al = getenv("RT_ALTERNATE")) ctx->alternate = atoi(al) != 0;
     if (const char* q = getenv("RT_QUEUED")) ctx->queued = atoi(q) != 0;
+    if (const char* q = getenv("RT_WG")) ctx->wg = atoi(q) != 0;
+    if (const char* q = getenv("RT_WG_NT")) ctx->wgTravWaves = atoi(q);
     if (const char* q = getenv("RT_Q_FLUSH")) ctx->qFlushMin = atoi(q);
     if (const char* q = getenv("RT_Q_REFILL")) ctx->qRefillMin = atoi(q);
     if (const char* q = getenv("RT_Q_STARVE")) ctx->qStarveMin = atoi(q);
@@ -378,6 +387,7 @@ void rt_destroy(RtContext* ctx)
     for (int i = 0; i < 2; i++) if (ctx->evAccWriter[i]) hipEventDestroy(ctx->evAccWriter[i]);
     hipFree(ctx->dPxCold);
     hipFree(ctx->dQRecords);
+    hipFree(ctx->dWgRecords);
     for (auto& pr : ctx->tuner.probe) {
         if (pr.start) hipEventDestroy(pr.start);
         if (pr.stop) hipEventDestroy(pr.stop);
@@ -1295,14 +1305,38 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
 #else
     const bool queued = false;
 #endif
-    const int variant = queued ? 6 + (ctx->stats ? 1 : 0) : (ctx->flatScene ? 2 : many ? 4 : 0) + (ctx->stats ? 1 : 0);
-    if (ctx->occBytes[variant] != stackBytes + 1) { /* occupancy query cached per (variant, LDS bytes) */
+    /* EXPERIMENT (make wg): eight-wave workgroups, traversal waves + shading waves around an LDS pool of parked chains */
+    size_t ldsBytes = stackBytes;
+    int blockThreads = RT_WAVE;
+#ifdef RT_WG_EXPERIMENT
+    const bool wgActive = ctx->wg && !ctx->flatScene && !many;
+    if (wgActive) {
+        kern = ctx->stats ? rtk::rt_trace_wg_kernel<true> : rtk::rt_trace_wg_kernel<false>;
+        kernHalf = kern;
+        a.wgTravWaves = ctx->wgTravWaves < 1 ? 1 : ctx->wgTravWaves > RT_WG_WAVES - 1 ? RT_WG_WAVES - 1 : ctx->wgTravWaves;
+        a.qFlushMin = ctx->qFlushMin < 1 ? 1 : ctx->qFlushMin > 64 ? 64 : ctx->qFlushMin;
+        a.qStarveMin = getenv("RT_Q_STARVE") ? (ctx->qStarveMin < 0 ? 0 : ctx->qStarveMin) : 64;
+        {   /* the largest pool that keeps three workgroups (24 waves) on a CU's 160 KB of LDS */
+            const size_t fixed = (size_t)a.wgTravWaves * ctx->stackEntries * RT_WAVE * sizeof(uint32_t) + sizeof(rtk::WgShared) + 16;
+            const size_t budget = 51 * 1024; /* 3 x 51 KB + allocation granules < 160 KB */
+            long long pool = budget > fixed ? (long long)((budget - fixed) / (RT_WG_REC * sizeof(uint32_t))) : 0;
+            if (const char* e = getenv("RT_WG_POOL")) pool = atoll(e);
+            a.wgPool = (int)(pool > RT_WG_POOL_MAX ? RT_WG_POOL_MAX : pool < 128 ? 128 : pool);
+        }
+        ldsBytes = ((size_t)a.wgTravWaves * ctx->stackEntries * RT_WAVE + (size_t)a.wgPool * RT_WG_REC) * sizeof(uint32_t) + sizeof(rtk::WgShared) + 16;
+        blockThreads = RT_WG_THREADS;
+    }
+#else
+    const bool wgActive = false;
+#endif
+    const int variant = wgActive ? 8 + (ctx->stats ? 1 : 0) : queued ? 6 + (ctx->stats ? 1 : 0) : (ctx->flatScene ? 2 : many ? 4 : 0) + (ctx->stats ? 1 : 0);
+    if (ctx->occBytes[variant] != ldsBytes + 1) { /* occupancy query cached per (variant, LDS bytes) */
         int perCU = 0;
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, RT_WAVE, stackBytes));
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, blockThreads, ldsBytes));
         ctx->occPerCU[variant] = perCU > 0 ? perCU : 1;
-        ctx->occBytes[variant] = stackBytes + 1;
+        ctx->occBytes[variant] = ldsBytes + 1;
         if (getenv("RT_DEBUG_LAUNCH"))
-            fprintf(stderr, "[rt] kernel variant %d: %d stack entries, %zu B of LDS per wave, %d waves per CU\n", variant, ctx->stackEntries, stackBytes, perCU);
+            fprintf(stderr, "[rt] kernel variant %d: %d stack entries, %zu B of LDS per workgroup of %d threads, %d workgroups per CU\n", variant, ctx->stackEntries, ldsBytes, blockThreads, perCU);
     }
     const long long resident = (long long)ctx->occPerCU[variant] * ctx->numCUs;
     {
@@ -1313,6 +1347,14 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
             HIP_TRY(ctx, hipMalloc(&ctx->dPxCold, (size_t)2 * waves * RT_COLD_STRIDE_BYTES));
             ctx->pxColdWaves = waves;
         }
+#ifdef RT_WG_EXPERIMENT
+        if (wgActive && ctx->wgUnits < waves) {
+            HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
+            hipFree(ctx->dWgRecords); ctx->dWgRecords = nullptr; ctx->wgUnits = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dWgRecords, (size_t)2 * waves * RT_WG_GLOBAL_DWORDS * sizeof(uint32_t)));
+            ctx->wgUnits = waves;
+        }
+#endif
 #ifdef RT_QUEUED_EXPERIMENT
         if (queued && ctx->qWaves < waves) {
             HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
@@ -1480,7 +1522,7 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
             }
         }
     }
-    const int parts = (!staged && twoOwn && tiles >= 2) ? 2 : 1;
+    const int parts = (!staged && twoOwn && tiles >= 2 && !wgActive) ? 2 : 1;
     if ((parts == 2 || lane == 1) && ctx->needFork) { /* the side stream follows what the main stream holds so far */
         HIP_TRY(ctx, hipEventRecord(ctx->evFork, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->sideStream, ctx->evFork, 0));
@@ -1547,8 +1589,21 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
             const int orc = order_acc_writer(q, parts == 1);
             if (orc) return orc;
         }
+#ifdef RT_WG_EXPERIMENT
+        if (wgActive) { /* its own tile counter from zero (the number of overshooting fetches of a workgroup launch is not fixed) */
+            a.qRecords = (uint32_t*)ctx->dWgRecords + (size_t)q * ctx->wgUnits * RT_WG_GLOBAL_DWORDS;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->dTileQueue + q, 0, sizeof(unsigned long long), st));
+            a.tileQueueBase = 0ull;
+        }
+#endif
         if (probe) hipEventRecord(probe->start, st);
-        hipLaunchKernelGGL(parts == 2 ? kernHalf : kern, dim3(grid), dim3(RT_WAVE), stackBytes, st, a);
+        hipLaunchKernelGGL(parts == 2 ? kernHalf : kern, dim3(grid), dim3(blockThreads), ldsBytes, st, a);
+#ifdef RT_WG_EXPERIMENT
+        if (wgActive) {
+            HIP_TRY(ctx, hipMemsetAsync(ctx->dTileQueue + q, 0, sizeof(unsigned long long), st));
+            ctx->tileQueueNext[q] = 0ull - ((unsigned long long)items + (a.queueStart ? (unsigned long long)grid : 0ull)); /* + the bookkeeping below = 0 */
+        }
+#endif
         if (probe) { hipEventRecord(probe->stop, st); probe->live = true; }
         HIP_TRY(ctx, hipGetLastError()); /* a refused launch ran no wave: the device counter did not move */
         /* every tile not taken by blockIdx is one successful fetch, and each of the grid waves overshoots once */
@@ -1838,6 +1893,9 @@ int rt_get_counters(RtContext* ctx, RtCounters* out)
     out->modelVisits = sum[5];
     out->pixelFrames = ctx->pixelFrames;
     out->gpuMs = ctx->gpuMs;
+#ifdef RT_WG_EXPERIMENT
+    if (sum[7]) return fail(ctx, RT_ERR_HIP, "workgroup kernel: the watchdog fired in %llu waves (a wave waited too long for the others)", sum[7]);
+#endif
     return RT_OK;
 }
 
