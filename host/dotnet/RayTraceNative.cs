@@ -127,6 +127,10 @@ namespace RayTraceHost
         [DllImport(Lib)] public static extern int rt_upload_scene(IntPtr ctx,
             [In] RtModel[] models, int n_models, [In] RtTriangle[] triangles, int n_triangles,
             [In] RtBVHNode[] nodes, int n_nodes, [In] RtSphere[] spheres, int n_spheres);
+        [StructLayout(LayoutKind.Sequential)] public struct RtSceneInfo { public int n_pairs, max_height, flat, n_filtered; public float prepare_ms; }
+        [DllImport(Lib)] public static extern int rt_validate_scene(
+            [In] RtModel[] models, int n_models, [In] RtTriangle[] triangles, int n_triangles,
+            [In] RtBVHNode[] nodes, int n_nodes, [In] RtSphere[] spheres, int n_spheres, out RtSceneInfo info);
         [DllImport(Lib)] public static extern int rt_update_models(IntPtr ctx, [In] RtModel[] models, int n_models);
         [DllImport(Lib)] public static extern int rt_update_spheres(IntPtr ctx, [In] RtSphere[] spheres, int n_spheres);
         [DllImport(Lib)] public static extern int rt_set_params(IntPtr ctx, ref RtParams p);

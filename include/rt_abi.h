@@ -202,6 +202,21 @@ int rt_upload_scene(RtContext* ctx,
                     const RtTriangle* triangles, int n_triangles,
                     const RtBVHNode* nodes, int n_nodes,
                     const RtSphere* spheres, int n_spheres);
+/* The host half of rt_upload_scene without a device: the same validation and re-layout (node pairs, pre-differenced
+ * triangles, root filters), nothing uploaded.  Returns the status rt_upload_scene would return for these buffers (message:
+ * rt_last_error(NULL)); out_info (may be NULL) describes what would be uploaded.  For hosts that want to check a scene
+ * before they own a GPU, and for the host-side tests. */
+typedef struct RtSceneInfo {
+    int32_t n_pairs;        /* sibling-pair records (64 bytes each) the traversal would fetch from */
+    int32_t max_height;     /* deepest BVH, in levels below a root: the traversal stack the scene needs */
+    int32_t flat;           /* 1: every model's root is a leaf (no traversal stack at all) */
+    int32_t n_filtered;     /* models behind the conservative root filter */
+    float prepare_ms;       /* host time of the validation + re-layout */
+} RtSceneInfo;
+int rt_validate_scene(const RtModel* models, int n_models,
+                      const RtTriangle* triangles, int n_triangles,
+                      const RtBVHNode* nodes, int n_nodes,
+                      const RtSphere* spheres, int n_spheres, RtSceneInfo* out_info);
 /* RCM:192-204 UpdateModels: refresh matrices + materials (offsets must not change). */
 int rt_update_models(RtContext* ctx, const RtModel* models, int n_models);
 /* Refresh sphere centres/radii/materials (extension; count must not change). */

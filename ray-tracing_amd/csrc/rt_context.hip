@@ -13,12 +13,16 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 #include <cmath>
 #include <string>
 #include <vector>
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
 
 #ifdef RT_WG_EXPERIMENT /* make wg: the queued stages with the parked chains in a workgroup-wide LDS pool (rt_kernels_wg.h) */
 #define RT_QUEUED_EXPERIMENT
@@ -763,6 +767,41 @@ static void make_chunks(const std::vector<DFilter>& filters, std::vector<DChunk>
     }
 }
 
+/* Uninitialised storage for plain records that are about to be written in full (std::vector::resize would first zero
+ * ~150 MB for a million triangles, on one thread: page faults, a third of rt_upload_scene's host time). */
+template <typename T>
+struct PodVec {
+    T* p = nullptr;
+    size_t n = 0;
+    PodVec() = default;
+    PodVec(const PodVec&) = delete;
+    PodVec& operator=(const PodVec&) = delete;
+    ~PodVec() { free(p); }
+    bool resize_uninit(size_t k)
+    {
+        free(p);
+        p = nullptr;
+        const size_t bytes = k * sizeof(T), huge = (size_t)2 << 20;
+        if (bytes >= 2 * huge) { /* fresh pages are the cost of a large scene's preparation: ask for 2 MB ones */
+            void* q = nullptr;
+            if (posix_memalign(&q, huge, (bytes + huge - 1) / huge * huge) == 0) {
+                madvise(q, (bytes + huge - 1) / huge * huge, MADV_HUGEPAGE);
+                p = static_cast<T*>(q);
+            }
+        } else if (k) {
+            p = static_cast<T*>(malloc(bytes));
+        }
+        n = p ? k : 0;
+        return k == 0 || p != nullptr;
+    }
+    void shrink(size_t k) { if (k < n) n = k; }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    size_t size() const { return n; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+};
+
 struct SceneBuilder {
     const RtBVHNode* nodes;
     int nNodes, nTris;
@@ -772,6 +811,14 @@ struct SceneBuilder {
     std::vector<int32_t> pairDepth;        /* height of the subtree below pair (levels) */
     std::vector<long long> pairLeafEnd;    /* largest startIndex + triangleCount of the leaves below pair (mesh-relative) */
     std::string error;
+    /* parallel conversion (one builder per mesh): pairs go into a segment of the scene's array, with their final ids; the memo
+     * covers only the mesh's own node window.  A mesh that leaves its window or overflows its segment sets `outside` and the
+     * caller falls back to the sequential walk, which has neither limit. */
+    DPair* seg = nullptr;
+    size_t segCap = 0, segCount = 0;
+    uint32_t idBase = 0;
+    int memoLo = 0;
+    bool outside = false;
 
     /* code of a leaf node whose triangles are [start, start+count) relative to triOffset */
     bool leaf_code(const RtBVHNode& n, int triOffset, uint32_t* code)
@@ -795,7 +842,7 @@ struct SceneBuilder {
 
     /* Converts the subtree under node `abs` (absolute index) of a mesh whose node 0 is at nodeOffset.
      * Returns its code and height (leaf = 0). Iterative post-order walk, memoised per sibling pair. */
-    bool convert(int nodeOffset, int triOffset, int absRoot, uint32_t* codeOut, int* heightOut)
+    bool convert(int nodeOffset, int triOffset, int absRoot, uint32_t* codeOut, int* heightOut, long long* endOut = nullptr)
     {
         struct Frame { int abs; int stage; int firstChild; uint32_t codeA, codeB; int hA, hB; long long endA; };
         std::vector<Frame> stack;
@@ -817,20 +864,21 @@ struct SceneBuilder {
                 long long fc = (long long)nodeOffset + n.startIndex;
                 if (n.startIndex < 0 || fc < 0 || fc + 1 >= nNodes) { error = "inner node child index out of bounds"; return false; }
                 f.firstChild = (int)fc;
-                int known = pairOfFirstChild[f.firstChild];
+                if (f.firstChild < memoLo || (size_t)(f.firstChild - memoLo) >= pairOfFirstChild.size()) { outside = true; error = "node outside the mesh's window"; return false; }
+                int known = pairOfFirstChild[f.firstChild - memoLo];
                 if (known == -2) { error = "cycle in BVH node graph"; return false; }
                 if (known >= 0) {
                     /* converted for an earlier model that shares these nodes: its leaves were range-checked
                      * against THAT model's triOffset, so check this one's against the subtree's largest leaf end */
-                    if ((long long)triOffset + pairLeafEnd[known] > nTris) { error = "leaf triangle range out of bounds"; return false; }
+                    if ((long long)triOffset + pairLeafEnd[known - idBase] > nTris) { error = "leaf triangle range out of bounds"; return false; }
                     retCode = (uint32_t)known;
-                    retHeight = pairDepth[known];
-                    retEnd = pairLeafEnd[known];
+                    retHeight = pairDepth[known - idBase];
+                    retEnd = pairLeafEnd[known - idBase];
                     stack.pop_back();
                     continue;
                 }
                 if ((int)stack.size() > RT_MAX_BVH_DEPTH + 1) { error = "BVH deeper than RT_MAX_BVH_DEPTH"; return false; }
-                pairOfFirstChild[f.firstChild] = -2;
+                pairOfFirstChild[f.firstChild - memoLo] = -2;
                 f.stage = 1;
                 int child = f.firstChild;
                 stack.push_back({child, 0, -1, 0, 0, 0, 0, 0});
@@ -856,12 +904,19 @@ struct SceneBuilder {
             memcpy(p.bMin, B.boundsMin, 12); memcpy(p.bMax, B.boundsMax, 12);
             p.codeA = f.codeA;
             p.codeB = f.codeB;
-            int id = (int)pairs.size();
-            pairs.push_back(p);
+            int id;
+            if (seg) {
+                if (segCount == segCap) { outside = true; error = "more node pairs than the mesh's window holds"; return false; }
+                seg[segCount] = p;
+                id = (int)(idBase + segCount++);
+            } else {
+                id = (int)pairs.size();
+                pairs.push_back(p);
+            }
             int h = 1 + (f.hA > f.hB ? f.hA : f.hB);
             pairDepth.push_back(h);
             pairLeafEnd.push_back(f.endA > retEnd ? f.endA : retEnd);
-            pairOfFirstChild[f.firstChild] = id;
+            pairOfFirstChild[f.firstChild - memoLo] = id;
             retCode = (uint32_t)id;
             retHeight = h;
             retEnd = pairLeafEnd.back();
@@ -869,9 +924,29 @@ struct SceneBuilder {
         }
         *codeOut = retCode;
         *heightOut = retHeight;
+        if (endOut) *endOut = retEnd;
         return true;
     }
 };
+
+/* host worker threads for the scene preparation: f(k) for k in [0, n), at most RT_HOST_THREADS (default 16) at a time */
+template <typename F>
+static void parallel_jobs(int n, F f)
+{
+    int nThreads = (int)std::thread::hardware_concurrency();
+    if (const char* e = getenv("RT_HOST_THREADS")) nThreads = atoi(e);
+    if (nThreads > 16) nThreads = 16;
+    if (nThreads > n) nThreads = n;
+    if (nThreads <= 1) {
+        for (int k = 0; k < n; k++) f(k);
+        return;
+    }
+    std::atomic<int> next(0);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nThreads; t++)
+        pool.emplace_back([&] { for (int k = next.fetch_add(1); k < n; k = next.fetch_add(1)) f(k); });
+    for (auto& th : pool) th.join();
+}
 
 template <typename T>
 static int upload_vec(RtContext* ctx, T** dptr, const void* src, size_t count)
@@ -908,9 +983,9 @@ struct PreparedScene {
     float sphereBound = 0;
     std::vector<DMaterial> mats;
     std::vector<DModel> dmodels;
-    std::vector<DPair> pairs;
-    std::vector<DTri> dtris;
-    std::vector<DTriN> dnorms;
+    PodVec<DPair> pairs;
+    PodVec<DTri> dtris;
+    PodVec<DTriN> dnorms;
     std::vector<uint32_t> bigLeaves;
     std::vector<DFilter> filters;
     std::vector<DChunk> chunks;
@@ -937,22 +1012,96 @@ static int prepare_scene(RtContext* ctx, const RtModel* models, int n_models, co
     sb.nodes = nodes;
     sb.nNodes = n_nodes;
     sb.nTris = n_triangles;
-    sb.pairOfFirstChild.assign((size_t)n_nodes + 1, -1);
     std::vector<uint32_t>& rootCodes = ps.rootCodes;
     std::vector<RtBVHNode>& rootChildren = ps.rootChildren;
     rootCodes.assign(n_models, 0u);
     rootChildren.assign((size_t)n_models * 2, RtBVHNode());
-    int maxHeight = 1;
+    std::vector<int> heights(n_models, 0);
     for (int i = 0; i < n_models; i++) {
         const RtModel& m = models[i];
         if (m.nodeOffset < 0 || m.nodeOffset >= n_nodes || m.triOffset < 0 || m.triOffset > n_triangles)
             return fail(ctx, RT_ERR_SCENE, "model %d: nodeOffset/triOffset out of range", i);
-        const RtBVHNode& root = nodes[m.nodeOffset];
-        if (root.triangleCount == 0)
+        if (nodes[m.nodeOffset].triangleCount == 0)
             return fail(ctx, RT_ERR_SCENE, "model %d: root node has triangleCount 0 (empty mesh) — undefined in the reference (RC:246)", i);
-        int height = 0;
-        if (!sb.convert(m.nodeOffset, m.triOffset, m.nodeOffset, &rootCodes[i], &height))
-            return fail(ctx, RT_ERR_SCENE, "model %d: %s", i, sb.error.c_str());
+    }
+    /* the distinct meshes (by root node), in the order the models name them */
+    struct MeshJob { int nodeOffset, triOffset, firstModel; size_t segStart = 0; SceneBuilder sb; uint32_t code = 0; int height = 0; long long leafEnd = 0; bool ok = false; };
+    std::vector<MeshJob> jobs;
+    std::vector<int> jobOfModel(n_models, 0);
+    for (int i = 0; i < n_models; i++) {
+        int j = 0;
+        while (j < (int)jobs.size() && jobs[j].nodeOffset != models[i].nodeOffset) j++;
+        if (j == (int)jobs.size()) { jobs.emplace_back(); jobs[j].nodeOffset = models[i].nodeOffset; jobs[j].triOffset = models[i].triOffset; jobs[j].firstModel = i; }
+        jobOfModel[i] = j;
+    }
+    bool merged = false;
+    size_t nPairs = 0;
+    if (jobs.size() >= 2 && jobs.size() <= 256 && n_nodes >= (1 << 16) && !getenv("RT_SEQUENTIAL_PREPARE")) {
+        /* large scene with several meshes: one worker per mesh.  A mesh's nodes are expected in the window from its root to the next
+         * mesh's root (how CreateAllMeshData lays them out, RCM:206-236); a window of w nodes holds at most w / 2 pairs, so every mesh
+         * gets its segment of ONE uninitialised pair array up front and writes final ids — nothing is merged or rebased. */
+        std::vector<int> order(jobs.size());
+        for (size_t j = 0; j < jobs.size(); j++) order[j] = (int)j;
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return jobs[x].nodeOffset < jobs[y].nodeOffset; });
+        std::vector<size_t> segStart(jobs.size() + 1, 0);
+        std::vector<int> winEnd(jobs.size(), n_nodes);
+        for (size_t k = 0; k < order.size(); k++) {
+            const int j = order[k];
+            winEnd[j] = k + 1 < order.size() ? jobs[order[k + 1]].nodeOffset : n_nodes;
+            jobs[j].segStart = segStart[k];
+            segStart[k + 1] = segStart[k] + (size_t)(winEnd[j] - jobs[j].nodeOffset) / 2 + 1;
+        }
+        if (segStart[order.size()] < ((size_t)1 << 26) && ps.pairs.resize_uninit(segStart[order.size()])) {
+            parallel_jobs((int)jobs.size(), [&](int j) {
+                MeshJob& mj = jobs[j];
+                mj.sb.nodes = nodes; mj.sb.nNodes = n_nodes; mj.sb.nTris = n_triangles;
+                mj.sb.memoLo = mj.nodeOffset;
+                mj.sb.pairOfFirstChild.assign((size_t)(winEnd[j] - mj.nodeOffset) + 1, -1);
+                mj.sb.seg = ps.pairs.data() + mj.segStart;
+                mj.sb.segCap = (size_t)(winEnd[j] - mj.nodeOffset) / 2 + 1;
+                mj.sb.idBase = (uint32_t)mj.segStart;
+                mj.sb.pairDepth.reserve(mj.sb.segCap);
+                mj.sb.pairLeafEnd.reserve(mj.sb.segCap);
+                mj.ok = mj.sb.convert(mj.nodeOffset, mj.triOffset, mj.nodeOffset, &mj.code, &mj.height, &mj.leafEnd);
+                memset(static_cast<void*>(mj.sb.seg + mj.sb.segCount), 0, (mj.sb.segCap - mj.sb.segCount) * sizeof(DPair)); /* the unused tail of the segment */
+            });
+            merged = true;
+            for (const MeshJob& mj : jobs)
+                if (mj.sb.outside || !mj.sb.bigLeaves.empty()) merged = false; /* (oversized leaves index a table the meshes would share) */
+        }
+    }
+    if (merged) {
+        for (int i = 0; i < n_models; i++) { /* errors in model order, as the sequential walk reports them */
+            const MeshJob& mj = jobs[jobOfModel[i]];
+            if (!mj.ok) return fail(ctx, RT_ERR_SCENE, "model %d: %s", i, mj.sb.error.c_str());
+            if ((long long)models[i].triOffset + mj.leafEnd > n_triangles) return fail(ctx, RT_ERR_SCENE, "model %d: leaf triangle range out of bounds", i);
+            rootCodes[i] = mj.code;
+            heights[i] = mj.height;
+        }
+        for (const MeshJob& mj : jobs)
+            if (mj.segStart + mj.sb.segCount > nPairs) nPairs = mj.segStart + mj.sb.segCount;
+        ps.pairs.shrink(nPairs);
+        jobs.clear();
+    } else {
+        jobs.clear();
+        sb.pairOfFirstChild.assign((size_t)n_nodes + 1, -1);
+        for (int i = 0; i < n_models; i++) {
+            const RtModel& m = models[i];
+            if (!sb.convert(m.nodeOffset, m.triOffset, m.nodeOffset, &rootCodes[i], &heights[i]))
+                return fail(ctx, RT_ERR_SCENE, "model %d: %s", i, sb.error.c_str());
+        }
+        nPairs = sb.pairs.size();
+        if (nPairs < ((size_t)1 << 26)) {
+            if (!ps.pairs.resize_uninit(nPairs)) return fail(ctx, RT_ERR_OOM, "rt_upload_scene: out of host memory");
+            if (nPairs) memcpy(static_cast<void*>(ps.pairs.data()), sb.pairs.data(), nPairs * sizeof(DPair));
+        }
+        std::vector<DPair>().swap(sb.pairs);
+    }
+    int maxHeight = 1;
+    for (int i = 0; i < n_models; i++) {
+        const RtModel& m = models[i];
+        const RtBVHNode& root = nodes[m.nodeOffset];
+        const int height = heights[i];
         if (height > RT_MAX_BVH_DEPTH) return fail(ctx, RT_ERR_SCENE, "model %d: BVH depth %d > %d", i, height, RT_MAX_BVH_DEPTH);
         if (height > maxHeight) maxHeight = height;
         if (!(rootCodes[i] & RT_CODE_LEAF)) {
@@ -979,32 +1128,39 @@ static int prepare_scene(RtContext* ctx, const RtModel* models, int n_models, co
         }
     }
 
+    const auto tConv = std::chrono::steady_clock::now();
     /* the kernels address pairs and triangles with 32-bit byte offsets from the array bases (rt_kernels.h) */
-    if (sb.pairs.size() >= ((size_t)1 << 26) || (size_t)n_triangles * sizeof(DTri) >= ((size_t)1 << 32))
-        return fail(ctx, RT_ERR_SCENE, "scene too large for 32-bit offsets: %zu node pairs (limit 2^26), %d triangles (limit 2^32 / 48)", sb.pairs.size(), n_triangles);
+    if (nPairs >= ((size_t)1 << 26) || (size_t)n_triangles * sizeof(DTri) >= ((size_t)1 << 32))
+        return fail(ctx, RT_ERR_SCENE, "scene too large for 32-bit offsets: %zu node pairs (limit 2^26), %d triangles (limit 2^32 / 48)", nPairs, n_triangles);
 
     /* ---- triangles: RC:190-192 are ray independent, pre-difference them (same fp32 ops) */
-    std::vector<DTri>& dtris = ps.dtris;
-    std::vector<DTriN>& dnorms = ps.dnorms;
-    dtris.resize((size_t)n_triangles);
-    dnorms.resize((size_t)n_triangles);
-    for (int i = 0; i < n_triangles; i++) {
-        const RtTriangle& t = triangles[i];
-        rt_f3 A = rt_v3(t.posA[0], t.posA[1], t.posA[2]);
-        rt_f3 B = rt_v3(t.posB[0], t.posB[1], t.posB[2]);
-        rt_f3 Cc = rt_v3(t.posC[0], t.posC[1], t.posC[2]);
-        rt_f3 ab = B - A, ac = Cc - A;
-        rt_f3 f = rt_cross(ab, ac);
-        DTri& d = dtris[i];
-        d.ax = A.x; d.ay = A.y; d.az = A.z;
-        d.abx = ab.x; d.aby = ab.y; d.abz = ab.z;
-        d.acx = ac.x; d.acy = ac.y; d.acz = ac.z;
-        d.fx = f.x; d.fy = f.y; d.fz = f.z;
-        memcpy(dnorms[i].n + 0, t.normA, 12);
-        memcpy(dnorms[i].n + 3, t.normB, 12);
-        memcpy(dnorms[i].n + 6, t.normC, 12);
-    }
+    PodVec<DTri>& dtris = ps.dtris;
+    PodVec<DTriN>& dnorms = ps.dnorms;
+    if (!dtris.resize_uninit((size_t)n_triangles) || !dnorms.resize_uninit((size_t)n_triangles))
+        return fail(ctx, RT_ERR_OOM, "rt_upload_scene: out of host memory");
+    const int triBlock = 1 << 15;
+    parallel_jobs((n_triangles + triBlock - 1) / triBlock, [&](int blk) {
+        const int i1 = (blk + 1) * triBlock < n_triangles ? (blk + 1) * triBlock : n_triangles;
+        for (int i = blk * triBlock; i < i1; i++) {
+            const RtTriangle& t = triangles[i];
+            rt_f3 A = rt_v3(t.posA[0], t.posA[1], t.posA[2]);
+            rt_f3 B = rt_v3(t.posB[0], t.posB[1], t.posB[2]);
+            rt_f3 Cc = rt_v3(t.posC[0], t.posC[1], t.posC[2]);
+            rt_f3 ab = B - A, ac = Cc - A;
+            rt_f3 f = rt_cross(ab, ac);
+            DTri& d = dtris[i];
+            d.ax = A.x; d.ay = A.y; d.az = A.z;
+            d.abx = ab.x; d.aby = ab.y; d.abz = ab.z;
+            d.acx = ac.x; d.acy = ac.y; d.acz = ac.z;
+            d.fx = f.x; d.fy = f.y; d.fz = f.z;
+            memcpy(dnorms[i].n + 0, t.normA, 12);
+            memcpy(dnorms[i].n + 3, t.normB, 12);
+            memcpy(dnorms[i].n + 6, t.normC, 12);
+        }
+    });
 
+    if (getenv("RT_DEBUG_UPLOAD"))
+        fprintf(stderr, "[rt] prepare_scene: triangles re-laid out in %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tConv).count());
     pack_spheres(spheres, n_spheres, ps.sph, &ps.sphereBound);
     ps.mats.resize((size_t)n_spheres + n_models);
     for (int i = 0; i < n_spheres; i++) pack_material(spheres[i].material, ps.mats[i]);
@@ -1016,7 +1172,6 @@ static int prepare_scene(RtContext* ctx, const RtModel* models, int n_models, co
     make_filters(models, n_models, rootCodes, rootChildren, spheres, n_spheres, ps.filters, &ps.maxOrigin);
     make_chunks(ps.filters, ps.chunks, &ps.nFiltered, &ps.extWords);
     ps.filters = append_filter_pairs(ps.filters); /* uploaded as one array */
-    ps.pairs.swap(sb.pairs);
     ps.bigLeaves.swap(sb.bigLeaves);
     ps.hModels.assign(models, models + n_models);
     ps.hSpheres.assign(spheres, spheres + n_spheres);
@@ -1030,8 +1185,8 @@ static int prepare_scene(RtContext* ctx, const RtModel* models, int n_models, co
 
 /* device copy of one scene array: from the host vector, or — `peer` — from the context that already holds it, device to
  * device on this context's stream (xGMI when the devices differ; the caller synchronises the stream) */
-template <typename T>
-static int commit_vec(RtContext* ctx, T** dptr, const std::vector<T>& v, T* const* peerPtr, const RtContext* peer)
+template <typename T, typename V>
+static int commit_vec(RtContext* ctx, T** dptr, const V& v, T* const* peerPtr, const RtContext* peer)
 {
     if (!peer) return upload_vec(ctx, dptr, v.data(), v.size());
     const size_t bytes = v.size() * sizeof(T);
@@ -1089,9 +1244,35 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     RT_FLUSH(ctx);
     PreparedScene ps;
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = prepare_scene(ctx, models, n_models, triangles, n_triangles, nodes, n_nodes, spheres, n_spheres, ps);
     if (rc) return rc;
-    return commit_scene(ctx, ps, nullptr);
+    const auto t1 = std::chrono::steady_clock::now();
+    rc = commit_scene(ctx, ps, nullptr);
+    if (getenv("RT_DEBUG_UPLOAD"))
+        fprintf(stderr, "[rt] rt_upload_scene: prepare %.2f ms, commit %.2f ms (%d triangles, %zu node pairs)\n",
+                std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(), n_triangles, ps.pairs.size());
+    return rc;
+}
+
+int rt_validate_scene(const RtModel* models, int n_models, const RtTriangle* triangles, int n_triangles,
+                      const RtBVHNode* nodes, int n_nodes, const RtSphere* spheres, int n_spheres, RtSceneInfo* out_info)
+{
+    PreparedScene ps;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = prepare_scene(nullptr, models, n_models, triangles, n_triangles, nodes, n_nodes, spheres, n_spheres, ps);
+    if (out_info) {
+        memset(out_info, 0, sizeof(*out_info));
+        out_info->prepare_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (rc == RT_OK) {
+            out_info->n_pairs = (int32_t)ps.pairs.size();
+            out_info->max_height = ps.maxHeight;
+            out_info->flat = ps.flat ? 1 : 0;
+            out_info->n_filtered = ps.nFiltered;
+        }
+    }
+    return rc;
 }
 
 int rt_update_models(RtContext* ctx, const RtModel* models, int n_models)

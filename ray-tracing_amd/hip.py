@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "rt_write_accumulated", "rt_timer_begin", "rt_timer_end",
     "rt_enable_stats", "rt_reset_counters", "rt_get_counters", "rt_build_bvh", "rt_build_bvh_mt", "rt_build_bvh_gpu", "rt_build_bvh_gpu_release", "rt_camera_view_params", "rt_version",
     "rt_debug_intersect", "rt_debug_math_eval", "rt_debug_phase_profile", "rt_build_bvh_gpu_batch",
-    "rt_flush",
+    "rt_flush", "rt_validate_scene",
     "rt_create_multi", "rt_destroy_multi", "rt_multi_count", "rt_multi_context", "rt_multi_resize", "rt_multi_upload_scene",
     "rt_multi_update_models", "rt_multi_update_spheres", "rt_multi_set_params", "rt_multi_reset_accumulation",
     "rt_multi_render_frame", "rt_multi_render_frames", "rt_multi_synchronize", "rt_gather_accumulated", "rt_gather_frame",
@@ -51,6 +51,7 @@ class HipApi(abi.CApi):
         "build_bvh_gpu_release": (None, []),
         "build_bvh_gpu_batch": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+        "validate_scene": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
         "debug_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
         "debug_math_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
         "debug_phase_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -84,6 +85,22 @@ class HipApi(abi.CApi):
         super().__init__(path, "rt_")
         for name, (res, args) in self._EXTRA.items():
             self._bind(name, res, args)
+
+    def validate_scene_arrays(self, models, triangles, nodes, spheres=None):
+        """rt_validate_scene: the host half of rt_upload_scene (no device needed).  Returns {n_pairs, max_height, flat, n_filtered,
+        prepare_ms}; raises RtError with the status and message rt_upload_scene would give."""
+        m, nm = abi._ptr(models, abi.model_dtype)
+        t, nt = abi._ptr(triangles, abi.triangle_dtype)
+        n, nn = abi._ptr(nodes, abi.node_dtype)
+        sp, ns = abi._ptr(spheres, abi.sphere_dtype)
+        class _Info(C.Structure):
+            _fields_ = [("n_pairs", C.c_int32), ("max_height", C.c_int32), ("flat", C.c_int32), ("n_filtered", C.c_int32), ("prepare_ms", C.c_float)]
+        info = _Info()
+        rc = self.validate_scene(m.ctypes.data if nm else None, nm, t.ctypes.data if nt else None, nt,
+                                 n.ctypes.data if nn else None, nn, sp.ctypes.data if ns else None, ns, C.byref(info))
+        if rc != abi.RT_OK:
+            raise abi.RtError(rc, (self.last_error(None) or b"").decode(errors="replace"))
+        return {k: getattr(info, k) for k, _ in _Info._fields_}
 
     def build_bvh_arrays_mt(self, verts, normals, indices, quality=abi.BVH_QUALITY_HIGH, threads=0):
         """rt_build_bvh_mt: same output as build_bvh_arrays, on `threads` host threads."""

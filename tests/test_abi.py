@@ -88,3 +88,90 @@ def test_product_never_touches_the_oracle(pkg):
             if f.endswith((".py", ".h", ".hip", ".cpp", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in text and "oracle_lib" not in text and "oracle/" not in text.replace("oracle/rt_oracle.cpp", ""), f
+
+
+def _scene_arrays(pkg, api, cfg=4, **kw):
+    sc = pkg.scenes.get(cfg, **kw)
+    mgr = sc.make_manager(None, api)
+    mgr.renderSeed = 1
+    return mgr.CreateAllMeshData(mgr.models), mgr._pack_spheres()
+
+
+def test_validate_scene_is_the_host_half_of_upload_scene(pkg, api, monkeypatch):
+    """rt_validate_scene needs no device: the same checks and the same re-layout as rt_upload_scene.  A large scene with several
+    meshes is converted on worker threads (one segment of the pair array per mesh); the sequential walk must see the same tree."""
+    a = pkg.abi
+    data, spheres = _scene_arrays(pkg, api, 4)                   # 81,920-triangle mesh + room: 166,010 nodes
+    assert len(data["nodes"]) >= 1 << 16 and len({int(m["nodeOffset"]) for m in data["meshInfo"]}) >= 2
+    infos = []
+    for env in ({}, {"RT_SEQUENTIAL_PREPARE": "1"}, {"RT_HOST_THREADS": "1"}):
+        for k in ("RT_SEQUENTIAL_PREPARE", "RT_HOST_THREADS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        infos.append(api.validate_scene_arrays(data["meshInfo"], data["triangles"], data["nodes"], spheres))
+    n_inner = int((data["nodes"]["triangleCount"] <= 0).sum())
+    for info in infos:
+        assert info["max_height"] == infos[1]["max_height"] >= 10 and info["flat"] == 0 and info["n_filtered"] == infos[1]["n_filtered"]
+    assert infos[1]["n_pairs"] == n_inner                       # the sequential walk: one pair per inner node
+    n_meshes = len({int(m["nodeOffset"]) for m in data["meshInfo"]})
+    assert n_inner <= infos[0]["n_pairs"] <= n_inner + 2 * n_meshes and infos[2]["n_pairs"] == infos[0]["n_pairs"]   # at most a slot of slack per mesh
+    small, sp = _scene_arrays(pkg, api, 3)
+    info = api.validate_scene_arrays(small["meshInfo"], small["triangles"], small["nodes"], sp)
+    assert info["n_pairs"] == int((small["nodes"]["triangleCount"] <= 0).sum()) and info["flat"] == 0
+    assert api.validate_scene_arrays(None, None, None, None) == {"n_pairs": 0, "max_height": 1, "flat": 1, "n_filtered": 0, "prepare_ms": pytest.approx(0, abs=50)}
+
+
+@pytest.mark.parametrize("sequential", [False, True])
+def test_validate_scene_refuses_what_upload_scene_refuses(pkg, api, monkeypatch, sequential):
+    import numpy as np
+    a = pkg.abi
+    if sequential:
+        monkeypatch.setenv("RT_SEQUENTIAL_PREPARE", "1")
+    else:
+        monkeypatch.delenv("RT_SEQUENTIAL_PREPARE", raising=False)
+    data, spheres = _scene_arrays(pkg, api, 4)
+    info, tris, nodes = data["meshInfo"], data["triangles"], data["nodes"]
+
+    def refused(models, triangles, nds, what):
+        with pytest.raises(a.RtError) as e:
+            api.validate_scene_arrays(models, triangles, nds, spheres)
+        assert e.value.status == a.RT_ERR_SCENE and what in str(e.value), str(e.value)
+
+    big = max(range(len(info)), key=lambda i: 0 if i + 1 == len(info) else int(info[i + 1]["nodeOffset"]) - int(info[i]["nodeOffset"]))
+    # a model that re-uses the big mesh with a triangle offset that runs its leaves past the buffer
+    bad = info.copy()
+    bad[-1]["nodeOffset"] = info[big]["nodeOffset"]
+    bad[-1]["triOffset"] = len(tris) - 1
+    refused(bad, tris, nodes, "out of bounds")
+    # a cycle: the root's first child names its own sibling pair as its children
+    root = int(info[big]["nodeOffset"])
+    first = root + int(nodes[root]["startIndex"])
+    assert nodes[root]["triangleCount"] <= 0 and nodes[first]["triangleCount"] <= 0
+    cyc = nodes.copy()
+    cyc[first]["startIndex"] = nodes[root]["startIndex"]
+    refused(info, tris, cyc, "cycle")
+    # a child index outside the node buffer, an empty mesh, a leaf past the triangle buffer, bad offsets
+    oob = nodes.copy()
+    oob[first]["startIndex"] = len(nodes)
+    refused(info, tris, oob, "child index out of bounds")
+    empty = nodes.copy()
+    empty[root]["triangleCount"] = 0
+    refused(info, tris, empty, "empty mesh")
+    refused(info, tris[: len(tris) // 2], nodes, "out of")
+    off = info.copy()
+    off[0]["nodeOffset"] = len(nodes)
+    refused(off, tris, nodes, "out of range")
+    # a mesh that reaches into another mesh's nodes (outside its window) is still a valid scene: the sequential walk takes over
+    if not sequential:
+        other = next(i for i in range(len(info)) if int(info[i]["nodeOffset"]) != root)
+        graft = nodes.copy()
+        o_root = int(info[other]["nodeOffset"])
+        if graft[o_root]["triangleCount"] <= 0:
+            # the other mesh's root now has the big mesh's root pair as children (indices are relative to ITS nodeOffset)
+            graft[o_root]["startIndex"] = first - o_root
+            try:
+                got = api.validate_scene_arrays(info, tris, graft, spheres)
+                assert got["n_pairs"] > 0
+            except a.RtError as e:      # only a triangle-range refusal is acceptable here (the grafted leaves use the other mesh's triOffset)
+                assert e.status == a.RT_ERR_SCENE and "out of bounds" in str(e)

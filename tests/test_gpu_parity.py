@@ -377,6 +377,47 @@ def test_scene_built_with_the_gpu_bvh_builder_renders_the_same_bits(pkg, api, or
     assert bits_equal(a, b)
 
 
+def test_parallel_scene_preparation_uploads_the_same_scene(pkg, api, monkeypatch):
+    """rt_upload_scene converts the meshes of a large scene (>= 65,536 nodes, several meshes) on worker threads, one pair array per
+    mesh, appended in mesh order; the sequential walk (RT_SEQUENTIAL_PREPARE=1) must give the same image and counters, a model that
+    re-uses a mesh with a triangle offset that runs past the buffer is refused by both, and so is a cycle in one of the meshes."""
+    a = pkg.abi
+    def tweak(mgr):
+        mgr.bvhOnGpu = True
+    imgs = []
+    for seq in (False, True):
+        if seq:
+            monkeypatch.setenv("RT_SEQUENTIAL_PREPARE", "1")
+        else:
+            monkeypatch.delenv("RT_SEQUENTIAL_PREPARE", raising=False)
+        g = api.create_tracer(0)
+        g.enable_stats(True)
+        img, mgr = render(pkg, api, g, 4, 96, 64, 2, tweak=tweak)
+        imgs.append((img, [g.counters()[k] for k in KEYS]))
+        data = mgr.CreateAllMeshData(mgr.models)
+        assert len(data["nodes"]) >= 1 << 16 and len({int(m["nodeOffset"]) for m in data["meshInfo"]}) >= 2
+        bad = data["meshInfo"].copy()
+        bad[-1]["nodeOffset"] = bad[0]["nodeOffset"]
+        bad[-1]["triOffset"] = len(data["triangles"]) - 1     # the big mesh's leaves now run past the end
+        with pytest.raises(a.RtError) as e:
+            g.upload_scene(bad, data["triangles"], data["nodes"])
+        assert e.value.status == a.RT_ERR_SCENE and b"out of bounds" in api.last_error(g.h)
+        nodes = data["nodes"].copy()
+        for m in data["meshInfo"]:                                 # a mesh whose root and root's first child are inner nodes
+            root = int(m["nodeOffset"])
+            first = root + int(nodes[root]["startIndex"])
+            if nodes[root]["triangleCount"] <= 0 and nodes[first]["triangleCount"] <= 0:
+                break
+        else:
+            raise AssertionError("no mesh with two inner levels")
+        nodes[first]["startIndex"] = nodes[root]["startIndex"]   # the root's first child names its own pair as children
+        with pytest.raises(a.RtError) as e:
+            g.upload_scene(data["meshInfo"], data["triangles"], nodes)
+        assert e.value.status == a.RT_ERR_SCENE and b"cycle" in api.last_error(g.h)
+        g.close()
+    assert bits_equal(imgs[0][0], imgs[1][0]) and imgs[0][1] == imgs[1][1]
+
+
 def test_config4_full_size_strip_sample(pkg, api, orc):
     """BASELINE config 4 as benchmarked: 1920x1080, depth of field on, the whole 81,920-triangle mesh."""
     sc = pkg.scenes.get(4)
