@@ -18,6 +18,11 @@
  *     array; subtree inner-node counts (bottom-up) and pre-order ranks (top-down) give every node its index.
  * The arithmetic (candidate planes, costs, strict comparisons, the (axis 0, pos 0) fallback) is the host builder's,
  * compiled with the same flags (no contraction, correctly rounded divide).
+ *
+ * Nothing in the level loop knows that there is ONE root: rt_build_bvh_gpu_batch builds the meshes of a scene as a FOREST —
+ * K roots at level 0 over the concatenated triangle array, every level's kernels run once for the nodes of all meshes, and
+ * the numbering and the statistics are kept per mesh (a node carries its mesh).  Twelve 82k-triangle meshes cost what one
+ * 983k-triangle mesh costs, not twelve times ~21 levels of small launches.
  */
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -28,6 +33,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include <mutex>
@@ -66,6 +72,7 @@ struct GNode { /* breadth-first record */
     int splitAxis;
     float splitPos;
     int nLeft;
+    int mesh;        /* which mesh of the batch (its root is node `mesh` of level 0) */
 };
 
 __device__ __forceinline__ float max3f(float a, float b, float c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
@@ -87,23 +94,36 @@ __device__ __forceinline__ void box_append(GBox& a, const GBox& o)
     a.nLeft += o.nLeft;
 }
 
-/* BVH:44-52 */
-__global__ void k_prepare(const float* verts, const int* indices, int ntri, GTri* tris, int* triNode)
+/* mesh of triangle t: triBase[k] <= t < triBase[k + 1] */
+__device__ __forceinline__ int mesh_of(const int* triBase, int nMeshes, int t)
+{
+    int lo = 0, hi = nMeshes - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (triBase[mid] <= t) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+/* BVH:44-52.  The batch's vertex and index arrays are concatenated; a mesh's indices are relative to its own vertices. */
+__global__ void k_prepare(const float* verts, const int* indices, int ntri, const int* triBase, const int* vertBase, int nMeshes, GTri* tris, int* triNode)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntri) return;
-    const float* a = verts + 3 * indices[3 * t + 0];
-    const float* b = verts + 3 * indices[3 * t + 1];
-    const float* c = verts + 3 * indices[3 * t + 2];
+    const int mesh = nMeshes > 1 ? mesh_of(triBase, nMeshes, t) : 0;
+    const float* vb = verts + 3 * (size_t)vertBase[mesh];
+    const float* a = vb + 3 * indices[3 * t + 0];
+    const float* b = vb + 3 * indices[3 * t + 1];
+    const float* c = vb + 3 * indices[3 * t + 2];
     GTri g;
     for (int k = 0; k < 3; k++) {
         g.c[k] = (a[k] + b[k] + c[k]) / 3;
         g.mn[k] = a[k] < b[k] ? (a[k] < c[k] ? a[k] : c[k]) : (b[k] < c[k] ? b[k] : c[k]);
         g.mx[k] = a[k] > b[k] ? (a[k] > c[k] ? a[k] : c[k]) : (b[k] > c[k] ? b[k] : c[k]);
     }
-    g.index = 3 * t;
+    g.index = 3 * t; /* position in the concatenated index array */
     tris[t] = g;
-    triNode[t] = 0;
+    triNode[t] = mesh; /* the roots are nodes 0 .. nMeshes-1 */
 }
 
 /* ChooseSplit's candidate planes (BVH:183-250), in evaluation order; slot 15 = the (0, 0) fallback */
@@ -323,8 +343,8 @@ __global__ void k_children(GNode* nodes, int first, int nActive, const int* spli
     memset(&l, 0, sizeof(l));
     memset(&r, 0, sizeof(r));
     for (int k = 0; k < 3; k++) { l.bmin[k] = b.lmn[k]; l.bmax[k] = b.lmx[k]; r.bmin[k] = b.rmn[k]; r.bmax[k] = b.rmx[k]; }
-    l.start = n.start; l.count = b.nLeft; l.depth = n.depth + 1; l.left = -1;
-    r.start = n.start + b.nLeft; r.count = n.count - b.nLeft; r.depth = n.depth + 1; r.left = -1;
+    l.start = n.start; l.count = b.nLeft; l.depth = n.depth + 1; l.left = -1; l.mesh = n.mesh;
+    r.start = n.start + b.nLeft; r.count = n.count - b.nLeft; r.depth = n.depth + 1; r.left = -1; r.mesh = n.mesh;
     nodes[li] = l;
     nodes[li + 1] = r;
 }
@@ -459,38 +479,55 @@ __global__ void k_number(GNode* nodes, int first, int count)
 __device__ __forceinline__ int wave_add(int v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
 __device__ __forceinline__ int wave_max(int v) { for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; } return v; }
 __device__ __forceinline__ int wave_min(int v) { for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t < v ? t : v; } return v; }
-__global__ void k_emit(const GNode* nodes, int total, RtBVHNode* out, int* stats /* leafCount, depthSum, depthMax, depthMin, triMax, triMin, triSum */)
+/* first node of every mesh in the output: a mesh has 1 + 2 * (inner nodes) nodes */
+__global__ void k_node_base(const GNode* nodes, int nMeshes, int* nodeBase)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    int acc = 0;
+    for (int k = 0; k < nMeshes; k++) { nodeBase[k] = acc; acc += 1 + 2 * nodes[k].innerCount; }
+    nodeBase[nMeshes] = acc;
+}
+__global__ void k_emit(const GNode* nodes, int total, const int* nodeBase, const int* triBase, RtBVHNode* out,
+                       int* stats /* per mesh: leafCount, depthSum, depthMax, depthMin, triMax, triMin, triSum, - */)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int leaf = 0, depth = 0, cnt = 0;
+    int leaf = 0, depth = 0, cnt = 0, mesh = -1;
     if (i < total) {
         const GNode& n = nodes[i];
+        mesh = n.mesh;
         RtBVHNode o;
         for (int k = 0; k < 3; k++) { o.boundsMin[k] = n.bmin[k]; o.boundsMax[k] = n.bmax[k]; }
         if (n.left >= 0) {
             o.startIndex = 1 + 2 * n.preIdx; /* BVH:165 */
-            o.triangleCount = i == 0 ? -1 : 0; /* the root keeps its constructor value (BVH:61) */
+            o.triangleCount = n.depth == 0 ? -1 : 0; /* the root keeps its constructor value (BVH:61) */
         } else {
-            o.startIndex = n.start;
+            o.startIndex = n.start - triBase[mesh]; /* relative to the mesh's first triangle */
             o.triangleCount = n.count;
             leaf = 1; depth = n.depth; cnt = n.count;
         }
-        out[n.id] = o;
+        out[nodeBase[mesh] + n.id] = o;
     }
-    /* BuildStats (BVH:557-575): one set of atomics per wave instead of seven per leaf on the same seven words */
-    const int leaves = wave_add(leaf);
-    if (leaves == 0) return;
-    const int dSum = wave_add(leaf ? depth : 0), tSum = wave_add(leaf ? cnt : 0);
-    const int dMax = wave_max(leaf ? depth : INT32_MIN), dMin = wave_min(leaf ? depth : INT32_MAX);
-    const int tMax = wave_max(leaf ? cnt : INT32_MIN), tMin = wave_min(leaf ? cnt : INT32_MAX);
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&stats[0], leaves);
-        atomicAdd(&stats[1], dSum);
-        atomicMax(&stats[2], dMax);
-        atomicMin(&stats[3], dMin);
-        atomicMax(&stats[4], tMax);
-        atomicMin(&stats[5], tMin);
-        atomicAdd(&stats[6], tSum);
+    /* BuildStats (BVH:557-575): one set of atomics per wave and mesh instead of seven per leaf on the same seven words
+     * (a level's nodes are grouped by mesh, so a wave rarely sees more than one) */
+    unsigned long long todo = __ballot(leaf != 0);
+    while (todo) {
+        const int m = __shfl(mesh, __ffsll((long long)todo) - 1, 64);
+        const bool mine = leaf && mesh == m;
+        const int leaves = wave_add(mine ? 1 : 0);
+        const int dSum = wave_add(mine ? depth : 0), tSum = wave_add(mine ? cnt : 0);
+        const int dMax = wave_max(mine ? depth : INT32_MIN), dMin = wave_min(mine ? depth : INT32_MAX);
+        const int tMax = wave_max(mine ? cnt : INT32_MIN), tMin = wave_min(mine ? cnt : INT32_MAX);
+        if ((threadIdx.x & 63) == 0) {
+            int* st = stats + 8 * m;
+            atomicAdd(&st[0], leaves);
+            atomicAdd(&st[1], dSum);
+            atomicMax(&st[2], dMax);
+            atomicMin(&st[3], dMin);
+            atomicMax(&st[4], tMax);
+            atomicMin(&st[5], tMin);
+            atomicAdd(&st[6], tSum);
+        }
+        todo &= ~__ballot(mine);
     }
 }
 __global__ void k_tri_index(const GTri* tris, int ntri, int* out)
@@ -529,7 +566,7 @@ struct DevBuf {
 
 static inline int blocks(size_t n, int t = 256) { return (int)((n + t - 1) / t); }
 
-struct Pool { int device = -1; DevBuf b[22]; };
+struct Pool { int device = -1; DevBuf b[23]; };
 /* ONE pool for the process, used under g_poolMutex (round 4, ADVICE r3: the pool was thread_local, so every short-lived worker
  * thread of a host that builds meshes on a thread pool left up to 4 GiB of device memory behind, and rt_build_bvh_gpu_release only
  * reached the calling thread's).  Builds from several threads therefore run one after the other — each one fills the GPU anyway. */
@@ -549,12 +586,51 @@ static void pool_release()
     g_pool.device = -1;
 }
 
-static int build_impl(int device, const float* verts, const float* normals, int n_verts, const int32_t* indices, int n_indices, int quality,
-          RtBVHNode* out_nodes, int* out_n_nodes, RtTriangle* out_tris, RtBvhStats* out_stats)
+struct MeshIn {
+    const float* verts;
+    const float* normals;
+    int n_verts;
+    const int32_t* indices;
+    int n_indices;
+};
+
+/* f(k) for k in [0, n) on at most `cap` host threads */
+template <typename F>
+static void host_parallel(int n, int cap, F f)
 {
-    if (!verts || !normals || !indices || !out_nodes || !out_n_nodes || !out_tris || n_verts < 0 || n_indices < 0 || n_indices % 3)
-        return RT_ERR_INVALID_ARG;
+    unsigned hc = std::thread::hardware_concurrency();
+    int nth = hc ? (int)hc : 1;
+    if (nth > cap) nth = cap;
+    if (nth > n) nth = n;
+    if (nth <= 1) {
+        for (int k = 0; k < n; k++) f(k);
+        return;
+    }
+    std::atomic<int> next(0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nth; t++)
+        th.emplace_back([&] { for (int k = next.fetch_add(1); k < n; k = next.fetch_add(1)) f(k); });
+    for (auto& t : th) t.join();
+}
+
+/* K >= 1 meshes as one forest.  Mesh k's nodes go to out_nodes + nodeOffset[k] (nodeOffset = running sum of the node counts),
+ * its triangles to out_tris + triBase[k]; out_n_nodes / out_node_offset / out_tri_offset / out_stats hold K entries (the offset
+ * arrays and out_stats may be null).  RT_BVH_QUALITY_DISABLED and empty meshes make their one-node tree on the host (K == 1 only;
+ * the batch entry builds such scenes mesh by mesh). */
+static int build_forest(int device, int K, const MeshIn* in, int quality, RtBVHNode* out_nodes, int* out_n_nodes, int* out_node_offset,
+                        RtTriangle* out_tris, int* out_tri_offset, RtBvhStats* out_stats)
+{
+    if (K < 1 || !in || !out_nodes || !out_n_nodes || !out_tris) return RT_ERR_INVALID_ARG;
     if (quality != RT_BVH_QUALITY_LOW && quality != RT_BVH_QUALITY_HIGH && quality != RT_BVH_QUALITY_DISABLED) return RT_ERR_INVALID_ARG;
+    std::vector<int> triBase(K + 1, 0), vertBase(K + 1, 0);
+    for (int k = 0; k < K; k++) {
+        const MeshIn& m = in[k];
+        if (!m.verts || !m.normals || !m.indices || m.n_verts < 0 || m.n_indices < 0 || m.n_indices % 3) return RT_ERR_INVALID_ARG;
+        const long long tb = (long long)triBase[k] + m.n_indices / 3, vb = (long long)vertBase[k] + m.n_verts;
+        if (tb > 0x2aaaaaaaLL || vb > 0x2aaaaaaaLL) return RT_ERR_SCENE; /* 3 * position must fit an int */
+        triBase[k + 1] = (int)tb;
+        vertBase[k + 1] = (int)vb;
+    }
     auto t0 = std::chrono::steady_clock::now();
     const bool dbg = getenv("RT_BVH_DEBUG") != nullptr;
     auto lap = [&](const char* what) {
@@ -564,54 +640,60 @@ static int build_impl(int device, const float* verts, const float* normals, int 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RT_ERR_NO_DEVICE;
     if (device < 0 || device >= ndev) return RT_ERR_INVALID_ARG;
     GB_TRY(hipSetDevice(device));
-    const int ntri = n_indices / 3;
+    const int ntri = triBase[K];
 
-    /* index validation + root bounds (BVH:53-58, in triangle order): ordered blocks of triangles on a few host threads,
-     * the blocks' boxes appended in order with the same strict comparisons (the first of equal values stays) */
-    float rmn[3] = {GB_FMAX, GB_FMAX, GB_FMAX}, rmx[3] = {-GB_FMAX, -GB_FMAX, -GB_FMAX};
-    {
-        unsigned hc = std::thread::hardware_concurrency();
-        int nth = hc ? (int)(hc > 8 ? 8 : hc) : 1;
-        if (nth > ntri / 16384) nth = ntri / 16384;
-        if (nth < 1) nth = 1;
-        struct Part { float mn[3], mx[3]; bool bad; };
-        std::vector<Part> parts(nth);
-        auto scan = [&](int k, int b0, int e0) {
-            Part& P = parts[k];
-            for (int d = 0; d < 3; d++) { P.mn[d] = GB_FMAX; P.mx[d] = -GB_FMAX; }
-            P.bad = false;
-            for (int t = b0; t < e0; t++) {
-                const int ia = indices[3 * t], ib = indices[3 * t + 1], ic = indices[3 * t + 2];
-                if (ia < 0 || ia >= n_verts || ib < 0 || ib >= n_verts || ic < 0 || ic >= n_verts) { P.bad = true; return; }
-                const float* a = verts + 3 * ia, * b = verts + 3 * ib, * c = verts + 3 * ic;
-                for (int d = 0; d < 3; d++) {
-                    float mn = a[d] < b[d] ? (a[d] < c[d] ? a[d] : c[d]) : (b[d] < c[d] ? b[d] : c[d]);
-                    float mx = a[d] > b[d] ? (a[d] > c[d] ? a[d] : c[d]) : (b[d] > c[d] ? b[d] : c[d]);
-                    if (mn < P.mn[d]) P.mn[d] = mn;
-                    if (mx > P.mx[d]) P.mx[d] = mx;
-                }
-            }
-        };
-        if (nth == 1) scan(0, 0, ntri);
-        else {
-            std::vector<std::thread> th;
-            for (int k = 0; k < nth; k++) th.emplace_back(scan, k, (int)((long long)ntri * k / nth), (int)((long long)ntri * (k + 1) / nth));
-            for (auto& t : th) t.join();
+    /* index validation + root bounds (BVH:53-58, in triangle order): ordered blocks of each mesh's triangles on a few host threads,
+     * a mesh's block boxes appended in order with the same strict comparisons (the first of equal values stays) */
+    struct Part { int mesh, b0, e0; float mn[3], mx[3]; bool bad; };
+    std::vector<Part> parts;
+    for (int k = 0; k < K; k++) {
+        const int nt = triBase[k + 1] - triBase[k];
+        int nb = nt / 16384;
+        if (nb > 8) nb = 8;
+        if (nb < 1) nb = 1;
+        for (int b = 0; b < nb; b++) {
+            Part P;
+            P.mesh = k; P.b0 = (int)((long long)nt * b / nb); P.e0 = (int)((long long)nt * (b + 1) / nb); P.bad = false;
+            parts.push_back(P);
         }
-        for (int k = 0; k < nth; k++) {
-            if (parts[k].bad) return RT_ERR_INVALID_ARG;
+    }
+    host_parallel((int)parts.size(), 16, [&](int pi) {
+        Part& P = parts[pi];
+        const MeshIn& m = in[P.mesh];
+        for (int d = 0; d < 3; d++) { P.mn[d] = GB_FMAX; P.mx[d] = -GB_FMAX; }
+        for (int t = P.b0; t < P.e0; t++) {
+            const int ia = m.indices[3 * t], ib = m.indices[3 * t + 1], ic = m.indices[3 * t + 2];
+            if (ia < 0 || ia >= m.n_verts || ib < 0 || ib >= m.n_verts || ic < 0 || ic >= m.n_verts) { P.bad = true; return; }
+            const float* a = m.verts + 3 * ia, * b = m.verts + 3 * ib, * c = m.verts + 3 * ic;
             for (int d = 0; d < 3; d++) {
-                if (parts[k].mn[d] < rmn[d]) rmn[d] = parts[k].mn[d];
-                if (parts[k].mx[d] > rmx[d]) rmx[d] = parts[k].mx[d];
+                float mn = a[d] < b[d] ? (a[d] < c[d] ? a[d] : c[d]) : (b[d] < c[d] ? b[d] : c[d]);
+                float mx = a[d] > b[d] ? (a[d] > c[d] ? a[d] : c[d]) : (b[d] > c[d] ? b[d] : c[d]);
+                if (mn < P.mn[d]) P.mn[d] = mn;
+                if (mx > P.mx[d]) P.mx[d] = mx;
             }
+        }
+    });
+    std::vector<GNode> roots(K);
+    for (int k = 0; k < K; k++) {
+        GNode& r = roots[k];
+        memset(&r, 0, sizeof(r));
+        for (int d = 0; d < 3; d++) { r.bmin[d] = GB_FMAX; r.bmax[d] = -GB_FMAX; }
+        r.start = triBase[k]; r.count = triBase[k + 1] - triBase[k]; r.depth = 0; r.left = -1; r.mesh = k;
+    }
+    for (const Part& P : parts) {
+        if (P.bad) return RT_ERR_INVALID_ARG;
+        GNode& r = roots[P.mesh];
+        for (int d = 0; d < 3; d++) {
+            if (P.mn[d] < r.bmin[d]) r.bmin[d] = P.mn[d];
+            if (P.mx[d] > r.bmax[d]) r.bmax[d] = P.mx[d];
         }
     }
 
     lap("validate + root box");
     std::vector<int> order(ntri);
-    std::vector<RtBVHNode> nodesOut; /* host-made trees (no BVH / empty mesh) */
-    size_t nNodesOut = 0;            /* nodes of the result, wherever they were written */
-    bool nodesInPlace = false;       /* the device tree was copied straight into out_nodes (no staging copy of ~21 MB at 327k triangles) */
+    std::vector<RtBVHNode> nodesOut; /* host-made tree (no BVH / empty mesh; K == 1) */
+    std::vector<int> nodeBase(K + 1, 0);
+    bool nodesInPlace = false;       /* the device trees were copied straight into out_nodes (no staging copy of ~21 MB at 327k triangles) */
     /* BVH:69-80: triangles in leaf order with vertex normals — host threads, started as soon as the order is known so that
      * they run while the node array is still on its way back from the device */
     std::vector<std::thread> gatherThreads;
@@ -623,17 +705,23 @@ static int build_impl(int device, const float* verts, const float* normals, int 
         if (threads > ntri / 8192) threads = ntri / 8192;
         if (threads < 1) threads = 1;
         const int* ord = order.data();
+        const int* tb = triBase.data();
         auto fill = [=](int b0, int e0) {
+            int k = 0;
+            while (k + 1 < K && tb[k + 1] <= b0) k++;
             for (int i = b0; i < e0; i++) {
-                const int b = ord[i];
+                while (tb[k + 1] <= i) k++; /* (empty meshes have no positions) */
+                const MeshIn& m = in[k];
+                const int b = ord[i] - 3 * tb[k]; /* position in the mesh's own index array */
                 RtTriangle& t = out_tris[i];
-                for (int k = 0; k < 3; k++) {
-                    t.posA[k] = verts[3 * indices[b + 0] + k];
-                    t.posB[k] = verts[3 * indices[b + 1] + k];
-                    t.posC[k] = verts[3 * indices[b + 2] + k];
-                    t.normA[k] = normals[3 * indices[b + 0] + k];
-                    t.normB[k] = normals[3 * indices[b + 1] + k];
-                    t.normC[k] = normals[3 * indices[b + 2] + k];
+                const int ia = m.indices[b + 0], ib = m.indices[b + 1], ic = m.indices[b + 2];
+                for (int c = 0; c < 3; c++) {
+                    t.posA[c] = m.verts[3 * ia + c];
+                    t.posB[c] = m.verts[3 * ib + c];
+                    t.posC[c] = m.verts[3 * ic + c];
+                    t.normA[c] = m.normals[3 * ia + c];
+                    t.normB[c] = m.normals[3 * ib + c];
+                    t.normC[c] = m.normals[3 * ic + c];
                 }
             }
         };
@@ -642,18 +730,23 @@ static int build_impl(int device, const float* verts, const float* normals, int 
             for (int t = 0; t < threads; t++) gatherThreads.emplace_back(fill, (int)((long long)ntri * t / threads), (int)((long long)ntri * (t + 1) / threads));
     };
     struct Joiner { std::vector<std::thread>& v; ~Joiner() { for (auto& t : v) if (t.joinable()) t.join(); } } joiner{gatherThreads}; /* every return path */
-    int statsH[7] = {0, 0, 0, INT32_MAX, 0, INT32_MAX, 0};
+    std::vector<int> statsH((size_t)8 * K);
+    for (int k = 0; k < K; k++) { int* st = &statsH[(size_t)8 * k]; st[0] = 0; st[1] = 0; st[2] = 0; st[3] = INT32_MAX; st[4] = 0; st[5] = INT32_MAX; st[6] = 0; st[7] = 0; }
     if (quality == RT_BVH_QUALITY_DISABLED || ntri == 0) { /* BVH:62-66 (and the empty mesh: Split makes the root a leaf) */
+        if (K != 1) return RT_ERR_INVALID_ARG; /* the batch entry builds these mesh by mesh */
         RtBVHNode root;
-        memcpy(root.boundsMin, rmn, 12);
-        memcpy(root.boundsMax, rmx, 12);
+        memcpy(root.boundsMin, roots[0].bmin, 12);
+        memcpy(root.boundsMax, roots[0].bmax, 12);
         root.startIndex = 0;
         root.triangleCount = ntri;
         nodesOut.push_back(root);
+        nodeBase[1] = 1;
         for (int t = 0; t < ntri; t++) order[t] = 3 * t;
         statsH[0] = (quality == RT_BVH_QUALITY_DISABLED) ? 0 : 1;
         if (quality != RT_BVH_QUALITY_DISABLED) { statsH[3] = 0; statsH[5] = 0; }
     } else {
+        for (int k = 0; k < K; k++)
+            if (roots[k].count == 0) return RT_ERR_INVALID_ARG; /* (K > 1: the batch entry keeps empty meshes out of the forest) */
         /* device scratch is kept between calls (a scene build calls this once per mesh): hipMalloc/hipFree of twenty
          * buffers would otherwise cost more than the build of a small mesh */
         Pool& pool = g_pool;
@@ -661,9 +754,10 @@ static int build_impl(int device, const float* verts, const float* normals, int 
         DevBuf &bVerts = pool.b[0], &bIdx = pool.b[1], &bTrisA = pool.b[2], &bTrisB = pool.b[3], &bNodeA = pool.b[4], &bNodeB = pool.b[5], &bFlag = pool.b[6],
                &bScan = pool.b[7], &bSrc = pool.b[8], &bNodes = pool.b[9], &bCands = pool.b[10], &bPartial = pool.b[11], &bChosen = pool.b[12], &bCounts = pool.b[13],
                &bBase = pool.b[14], &bChunkNode = pool.b[15], &bSplit = pool.b[16], &bRank = pool.b[17], &bFirstR = pool.b[18], &bTemp = pool.b[19], &bMisc = pool.b[20],
-               &bOut = pool.b[21];
-        float* dVerts = bVerts.get<float>((size_t)n_verts * 3 + 1);
-        int* dIdx = bIdx.get<int>((size_t)n_indices + 1);
+               &bOut = pool.b[21], &bTables = pool.b[22];
+        const int nVertsAll = vertBase[K];
+        float* dVerts = bVerts.get<float>((size_t)nVertsAll * 3 + 1);
+        int* dIdx = bIdx.get<int>((size_t)ntri * 3 + 1);
         GTri* trisA = bTrisA.get<GTri>(ntri);
         GTri* trisB = bTrisB.get<GTri>(ntri);
         int* nodeOfA = bNodeA.get<int>(ntri);
@@ -671,24 +765,24 @@ static int build_impl(int device, const float* verts, const float* normals, int 
         int* flag = bFlag.get<int>((size_t)ntri + 1);
         int* S = bScan.get<int>((size_t)ntri + 1);
         int* src = bSrc.get<int>(ntri);
-        const size_t maxNodes = 2 * (size_t)ntri + 66; /* 2*ntri - 1 for a well-formed tree; empty-child chains are refused below */
+        const size_t maxNodes = 2 * (size_t)ntri + 66 * (size_t)K; /* 2*ntri - 1 per well-formed tree; empty-child chains are refused below */
         GNode* nodes = bNodes.get<GNode>(maxNodes);
-        int* misc = bMisc.get<int>(16);
-        if (!dVerts || !dIdx || !trisA || !trisB || !nodeOfA || !nodeOfB || !flag || !S || !src || !nodes || !misc) return RT_ERR_OOM;
-        GB_TRY(hipMemcpy(dVerts, verts, sizeof(float) * 3 * (size_t)n_verts, hipMemcpyHostToDevice));
-        GB_TRY(hipMemcpy(dIdx, indices, sizeof(int) * (size_t)n_indices, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_prepare, dim3(blocks(ntri)), dim3(256), 0, 0, dVerts, dIdx, ntri, trisA, nodeOfA);
-        GNode root;
-        memset(&root, 0, sizeof(root));
-        memcpy(root.bmin, rmn, 12);
-        memcpy(root.bmax, rmx, 12);
-        root.start = 0; root.count = ntri; root.depth = 0; root.left = -1;
-        GB_TRY(hipMemcpy(nodes, &root, sizeof(GNode), hipMemcpyHostToDevice));
+        int* misc = bMisc.get<int>((size_t)8 * K + 16);
+        int* tables = bTables.get<int>((size_t)3 * (K + 1)); /* triBase | vertBase | nodeBase */
+        if (!dVerts || !dIdx || !trisA || !trisB || !nodeOfA || !nodeOfB || !flag || !S || !src || !nodes || !misc || !tables) return RT_ERR_OOM;
+        int* dTriBase = tables, * dVertBase = tables + (K + 1), * dNodeBase = tables + 2 * (K + 1);
+        for (int k = 0; k < K; k++) {
+            if (in[k].n_verts) GB_TRY(hipMemcpy(dVerts + 3 * (size_t)vertBase[k], in[k].verts, sizeof(float) * 3 * (size_t)in[k].n_verts, hipMemcpyHostToDevice));
+            if (in[k].n_indices) GB_TRY(hipMemcpy(dIdx + 3 * (size_t)triBase[k], in[k].indices, sizeof(int) * (size_t)in[k].n_indices, hipMemcpyHostToDevice));
+        }
+        GB_TRY(hipMemcpy(dTriBase, triBase.data(), sizeof(int) * (size_t)(K + 1), hipMemcpyHostToDevice));
+        GB_TRY(hipMemcpy(dVertBase, vertBase.data(), sizeof(int) * (size_t)(K + 1), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_prepare, dim3(blocks(ntri)), dim3(256), 0, 0, dVerts, dIdx, ntri, dTriBase, dVertBase, K, trisA, nodeOfA);
+        GB_TRY(hipMemcpy(nodes, roots.data(), sizeof(GNode) * (size_t)K, hipMemcpyHostToDevice));
 
         lap("alloc + upload");
         std::vector<int> levelFirst;
-        int first = 0, nActive = 1, total = 1;
-        GB_TRY(hipMemsetAsync(misc, 0, 16 * sizeof(int), 0));
+        int first = 0, nActive = K, total = K;
         size_t tempBytes = 0;
         hipcub::DeviceScan::ExclusiveSum(nullptr, tempBytes, flag, S, ntri + 1);
         void* temp = bTemp.get<char>(tempBytes + 256);
@@ -749,7 +843,7 @@ static int build_impl(int device, const float* verts, const float* normals, int 
         }
         GB_TRY(hipGetLastError());
         if (dbg) { hipDeviceSynchronize(); lap("levels"); }
-        /* numbering */
+        /* numbering, per mesh: every root is pre-order rank 0, node 0 of ITS tree */
         for (int l = (int)levelFirst.size() - 1; l >= 0; l--) {
             const int lf = levelFirst[l], le = (l + 1 < (int)levelFirst.size()) ? levelFirst[l + 1] : total;
             if (le > lf) hipLaunchKernelGGL(k_inner_count, dim3(blocks(le - lf)), dim3(256), 0, 0, nodes, lf, le - lf);
@@ -758,62 +852,84 @@ static int build_impl(int device, const float* verts, const float* normals, int 
             const int lf = levelFirst[l], le = (l + 1 < (int)levelFirst.size()) ? levelFirst[l + 1] : total;
             if (le > lf) hipLaunchKernelGGL(k_number, dim3(blocks(le - lf)), dim3(256), 0, 0, nodes, lf, le - lf);
         }
+        hipLaunchKernelGGL(k_node_base, dim3(1), dim3(64), 0, 0, nodes, K, dNodeBase);
         RtBVHNode* dOut = bOut.get<RtBVHNode>(total);
         if (!dOut) return RT_ERR_OOM;
-        GB_TRY(hipMemcpy(misc, statsH, sizeof(statsH), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_emit, dim3(blocks(total)), dim3(256), 0, 0, nodes, total, dOut, misc);
+        GB_TRY(hipMemcpy(misc, statsH.data(), sizeof(int) * statsH.size(), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_emit, dim3(blocks(total)), dim3(256), 0, 0, nodes, total, dNodeBase, dTriBase, dOut, misc);
         hipLaunchKernelGGL(k_tri_index, dim3(blocks(ntri)), dim3(256), 0, 0, trisA, ntri, S);
         GB_TRY(hipGetLastError());
-        if ((size_t)total > 2 * (size_t)(ntri > 0 ? ntri : 1)) return RT_ERR_SCENE; /* out_nodes holds 2 * ntri nodes; as rt_build_bvh */
+        GB_TRY(hipMemcpy(nodeBase.data(), dNodeBase, sizeof(int) * (size_t)(K + 1), hipMemcpyDeviceToHost));
+        if (nodeBase[K] != total) return RT_ERR_HIP; /* (cannot happen: every node belongs to one mesh's tree) */
+        for (int k = 0; k < K; k++) /* a mesh's part of out_nodes holds 2 * its triangles; as rt_build_bvh */
+            if ((size_t)(nodeBase[k + 1] - nodeBase[k]) > 2 * (size_t)(triBase[k + 1] - triBase[k])) return RT_ERR_SCENE;
         GB_TRY(hipMemcpy(order.data(), S, sizeof(int) * (size_t)ntri, hipMemcpyDeviceToHost));
         start_gather();
         GB_TRY(hipMemcpy(out_nodes, dOut, sizeof(RtBVHNode) * (size_t)total, hipMemcpyDeviceToHost));
         nodesInPlace = true;
-        nNodesOut = (size_t)total;
-        GB_TRY(hipMemcpy(statsH, misc, sizeof(statsH), hipMemcpyDeviceToHost));
+        GB_TRY(hipMemcpy(statsH.data(), misc, sizeof(int) * statsH.size(), hipMemcpyDeviceToHost));
         lap("numbering + readback");
     }
-    if (!nodesInPlace) nNodesOut = nodesOut.size();
-    if (nNodesOut > 2 * (size_t)(ntri > 0 ? ntri : 1) || (ntri > 0 && statsH[0] > 0 && statsH[5] == 0)) { /* as rt_build_bvh */
-        *out_n_nodes = 0;
-        return RT_ERR_SCENE;
+    for (int k = 0; k < K; k++) {
+        const int* st = &statsH[(size_t)8 * k];
+        const int nt = triBase[k + 1] - triBase[k];
+        if ((size_t)(nodeBase[k + 1] - nodeBase[k]) > 2 * (size_t)(nt > 0 ? nt : 1) || (nt > 0 && st[0] > 0 && st[5] == 0)) { /* as rt_build_bvh */
+            for (int q = 0; q < K; q++) out_n_nodes[q] = 0;
+            return RT_ERR_SCENE;
+        }
     }
     if (!gatherStarted) start_gather();
     if (!nodesInPlace) memcpy(out_nodes, nodesOut.data(), nodesOut.size() * sizeof(RtBVHNode));
-    *out_n_nodes = (int)nNodesOut;
     for (auto& t : gatherThreads) t.join();
     gatherThreads.clear();
     lap("triangle gather");
-    if (out_stats) {
-        memset(out_stats, 0, sizeof(*out_stats));
-        out_stats->triangleCount = statsH[6];
-        out_stats->totalNodeCount = (int)nNodesOut - (quality == RT_BVH_QUALITY_DISABLED ? 1 : 0);
-        out_stats->leafNodeCount = statsH[0];
-        out_stats->leafDepthMax = statsH[2];
-        out_stats->leafDepthMin = statsH[3];
-        out_stats->leafDepthSum = statsH[1];
-        out_stats->leafMaxTriCount = statsH[4];
-        out_stats->leafMinTriCount = statsH[5];
-        out_stats->quality = quality;
-        out_stats->timeMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (int k = 0; k < K; k++) {
+        out_n_nodes[k] = nodeBase[k + 1] - nodeBase[k];
+        if (out_node_offset) out_node_offset[k] = nodeBase[k];
+        if (out_tri_offset) out_tri_offset[k] = triBase[k];
+        if (out_stats) {
+            const int* st = &statsH[(size_t)8 * k];
+            RtBvhStats& o = out_stats[k];
+            memset(&o, 0, sizeof(o));
+            o.triangleCount = st[6];
+            o.totalNodeCount = out_n_nodes[k] - (quality == RT_BVH_QUALITY_DISABLED ? 1 : 0);
+            o.leafNodeCount = st[0];
+            o.leafDepthMax = st[2];
+            o.leafDepthMin = st[3];
+            o.leafDepthSum = st[1];
+            o.leafMaxTriCount = st[4];
+            o.leafMinTriCount = st[5];
+            o.quality = quality;
+            o.timeMs = ntri > 0 ? ms * (double)(triBase[k + 1] - triBase[k]) / (double)ntri : ms; /* the batch's time, by share of the triangles */
+        }
     }
     return RT_OK;
+}
+
+/* pool lock, caller's device restored, scratch released when it grew beyond GB_POOL_KEEP */
+static int build_locked(int device, int K, const MeshIn* in, int quality, RtBVHNode* out_nodes, int* out_n_nodes, int* out_node_offset,
+                        RtTriangle* out_tris, int* out_tri_offset, RtBvhStats* out_stats)
+{
+    std::lock_guard<std::mutex> poolLock(g_poolMutex);
+    int prev = -1;
+    const bool havePrev = hipGetDevice(&prev) == hipSuccess; /* the caller's current device is the caller's business: put it back */
+    if (out_n_nodes) for (int k = 0; k < K; k++) out_n_nodes[k] = 0; /* every error path leaves 0 nodes */
+    const int rc = build_forest(device, K, in, quality, out_nodes, out_n_nodes, out_node_offset, out_tris, out_tri_offset, out_stats);
+    if (rc != RT_OK && out_n_nodes) for (int k = 0; k < K; k++) out_n_nodes[k] = 0;
+    size_t held = 0;
+    for (const DevBuf& d : g_pool.b) held += d.cap;
+    if (held > GB_POOL_KEEP) pool_release(); /* a huge mesh does not pin its scratch for the life of the process */
+    if (havePrev) hipSetDevice(prev);
+    return rc;
 }
 
 int build(int device, const float* verts, const float* normals, int n_verts, const int32_t* indices, int n_indices, int quality,
           RtBVHNode* out_nodes, int* out_n_nodes, RtTriangle* out_tris, RtBvhStats* out_stats)
 {
-    std::lock_guard<std::mutex> poolLock(g_poolMutex);
-    int prev = -1;
-    const bool havePrev = hipGetDevice(&prev) == hipSuccess; /* the caller's current device is the caller's business: put it back */
-    if (out_n_nodes) *out_n_nodes = 0;                       /* every error path leaves 0 nodes */
-    const int rc = build_impl(device, verts, normals, n_verts, indices, n_indices, quality, out_nodes, out_n_nodes, out_tris, out_stats);
-    if (rc != RT_OK && out_n_nodes) *out_n_nodes = 0;
-    size_t held = 0;
-    for (const DevBuf& d : g_pool.b) held += d.cap;
-    if (held > GB_POOL_KEEP) pool_release(); /* a huge mesh does not pin its scratch for the life of the thread */
-    if (havePrev) hipSetDevice(prev);
-    return rc;
+    if (!out_n_nodes) return RT_ERR_INVALID_ARG;
+    const MeshIn m = {verts, normals, n_verts, indices, n_indices};
+    return build_locked(device, 1, &m, quality, out_nodes, out_n_nodes, nullptr, out_tris, nullptr, out_stats);
 }
 
 } // namespace gbvh
@@ -833,9 +949,26 @@ extern "C" int rt_build_bvh_gpu_batch(int device_id, int n_meshes, const float* 
     if (n_meshes < 0 || (n_meshes > 0 && (!verts || !normals || !n_verts || !indices || !n_indices || !out_nodes || !out_n_nodes || !out_node_offset ||
                                           !out_tris || !out_tri_offset)))
         return RT_ERR_INVALID_ARG;
-    long long nodeOff = 0, triOff = 0;
+    if (n_meshes == 0) return RT_OK;
+    bool forest = n_meshes > 1 && quality != RT_BVH_QUALITY_DISABLED && !getenv("RT_BVH_NO_FOREST");
+    long long tris = 0;
     for (int k = 0; k < n_meshes; k++) {
         if (n_indices[k] < 0 || n_indices[k] % 3) return RT_ERR_INVALID_ARG;
+        if (n_indices[k] == 0) forest = false; /* an empty mesh's one-node tree is made on the host */
+        tris += n_indices[k] / 3;
+    }
+    if (tris > 0x2aaaaaaaLL) forest = false;
+    if (forest) {
+        /* all meshes as one forest: every level's kernels run once for the whole scene */
+        std::vector<gbvh::MeshIn> in(n_meshes);
+        for (int k = 0; k < n_meshes; k++) in[k] = {verts[k], normals[k], n_verts[k], indices[k], n_indices[k]};
+        const int rc = gbvh::build_locked(device_id, n_meshes, in.data(), quality, out_nodes, out_n_nodes, out_node_offset, out_tris, out_tri_offset, out_stats);
+        if (rc == RT_OK) return rc;
+        /* refused (an index out of range, a degenerate mesh, no memory for the whole scene at once): mesh by mesh, so that the
+         * status and the meshes written before the offending one are what they always were */
+    }
+    long long nodeOff = 0, triOff = 0;
+    for (int k = 0; k < n_meshes; k++) {
         out_node_offset[k] = (int)nodeOff;
         out_tri_offset[k] = (int)triOff;
         out_n_nodes[k] = 0;

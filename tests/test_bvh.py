@@ -3,6 +3,8 @@ literal restatement of BVH.cs in the oracle, and the oracle's traversal finds th
 same closest hit as brute force over all triangles (property test)."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -230,6 +232,30 @@ def test_gpu_batch_builder_writes_the_concatenated_arrays(pkg, api):
             assert s1 == stats
             no, to = no + len(n1), to + len(t1)
         assert len(nd) == no and len(tr) == to
+    # the forest path with every awkward mesh class at once (soup, identical triangles, flat, point, one triangle), in both orders,
+    # and the mesh-by-mesh path (RT_BVH_NO_FOREST) for the same batch
+    cases = mesh_cases(pkg)
+    for order in (cases, cases[::-1]):
+        for env in (None, "1"):
+            if env:
+                os.environ["RT_BVH_NO_FOREST"] = env
+            try:
+                nd, tr, per = api.build_bvh_arrays_gpu_batch([(m.vertices, m.normals, m.triangles) for m in order], 1)
+            finally:
+                os.environ.pop("RT_BVH_NO_FOREST", None)
+            no = to = 0
+            for m, (noff, toff, stats) in zip(order, per):
+                n1, t1, s1 = api.build_bvh_arrays(m.vertices, m.normals, m.triangles, 1)
+                assert (noff, toff) == (no, to)
+                assert nd[no:no + len(n1)].tobytes() == n1.tobytes() and tr[to:to + len(t1)].tobytes() == t1.tobytes(), (m.name, env)
+                s1.pop("timeMs"), stats.pop("timeMs")
+                assert s1 == stats, (m.name, env)
+                no, to = no + len(n1), to + len(t1)
+            assert len(nd) == no and len(tr) == to
+    # an empty mesh in the batch: its one-node tree comes from the host, the batch goes mesh by mesh
+    empty = pkg.meshes.Mesh(np.zeros((3, 3), np.float32), np.zeros((3, 3), np.float32), np.zeros(0, np.int32), "empty")
+    nd, tr, per = api.build_bvh_arrays_gpu_batch([(m.vertices, m.normals, m.triangles) for m in (meshes[0], empty, meshes[2])], 1)
+    assert [p[0] for p in per] == [0, per[1][0], per[1][0] + 1] and per[1][2]["triangleCount"] == 0
     # an empty batch is fine; a bad mesh in the middle reports its error
     nd, tr, per = api.build_bvh_arrays_gpu_batch([], 1)
     assert len(nd) == 0 and len(tr) == 0 and per == []
