@@ -100,6 +100,141 @@ def translation_unit():
             % (os.path.join(HERE, "ref_compat.h"), "\n".join(parts), os.path.join(HERE, "ref_driver.h")))
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's BVH builder (C#): Assets/Scripts/Types/BVH.cs -> oracle/_ref/libref_bvh.so
+BVH_SOURCE = os.path.join(REFERENCE, "Assets", "Scripts", "Types", "BVH.cs")
+BVH_TYPES = ("Node", "BVHTriangle", "Triangle", "NodeList", "BuildStats")   # nested types, in dependency order
+BVH_CUT = (r"public \(bool hit, float dst, Vector3 pos, bool backface, Vector3 normal\) Search\(",   # BVH:321-375  CPU-side traversal:
+           r"public static \(bool hit, float dst\) RayBoundingBox\(",                                # BVH:377-401  not on the build path
+           r"static \(bool hit, float dst, bool backface, Vector3 normal\) RayTriangle\(",           # BVH:403-424  (and C# tuples / Stack<T>)
+           r"public override string ToString\(\)")                                                 # BVH:555-575  interpolated strings
+
+
+def _block(text, header_regex):
+    """(start, end) of the declaration whose header matches: from the start of the header's line to its closing brace"""
+    m = re.search(header_regex, text)
+    if not m:
+        raise SystemExit("BVH.cs: %r not found — the reference changed, review oracle/make_ref.py" % header_regex)
+    start = text.rfind("\n", 0, m.start()) + 1
+    i = text.index("{", m.end())
+    depth = 0
+    while True:
+        if text[i] == "{":
+            depth += 1
+        elif text[i] == "}":
+            depth -= 1
+            if depth == 0:
+                return start, i + 1
+        i += 1
+
+
+def rewrite_bvh(text):
+    """The complete list of edits made to BVH.cs.  Syntax only: no expression, statement, constant or statement order changes.
+
+     B1. `using ...;` lines and the `[System.Serializable]` attribute dropped; `namespace A.B` -> `namespace A::B`
+     B2. the members that are not on the build path are cut whole: Search, RayBoundingBox, RayTriangle (CPU-side traversal, BVH:321-424)
+         and BuildStats.ToString (BVH:555-575)
+     B3. the nested types Node, BVHTriangle, Triangle, NodeList, BuildStats are moved in front of the fields that use them (C++ wants
+         complete member types) and every type's closing brace gets its `;`
+     B4. `public`, `readonly`, `private`, `override` dropped; `class` -> `struct`; `enum` -> `enum class`
+     B5. `T[]` -> `CsArray<T>`; `new T[n]` -> `CsArray<T>(n)`
+     B6. `new T(args)` -> `T(args)`; target-typed `T x = new(args);` -> `T x = T(args);`; `x = new();` -> `x = {};`
+     B7. `ref T x = ref e;` -> `T& x = e;`
+     B8. `var` -> `auto`; `System.Diagnostics.Stopwatch.StartNew()` -> `Stopwatch::StartNew()`
+     B9. `float.MaxValue / MinValue / PositiveInfinity`, `int.MaxValue` -> CS_FLOAT_MAX / CS_FLOAT_MIN / CS_FLOAT_POSITIVE_INFINITY / CS_INT_MAX
+    B10. the literal `1f` -> `1.0f`
+    B11. tuples: return type `(int axis, float pos, float cost)` -> `std::tuple<int, float, float>`, `return (a, b, c);` ->
+         `return std::make_tuple(a, b, c);`, `(int a, float b, float c) = f(...)` -> `auto [a, b, c] = f(...)`
+    B12. switch expressions `x switch { 0 => a, 1 => b, _ => c }` -> `(x == 0 ? a : x == 1 ? b : c)`
+    B13. static member access `Mathf.` `Math.` `Quality.` -> `::`; `Array.Resize(ref a, n)` -> `Array::Resize(a, n)`
+    B14. `this.` -> `this->`
+    B15. the expression-bodied property `int NodeCount => Index;` -> a member function, its use gets `()`
+    B16. `int` / `float` fields and locals declared without initialiser get `{}` (C# zero-initialises fields; locals are assigned
+         before use, so it changes nothing for them)
+    B17. BuildStats' field `Quality` is renamed `Quality_` (a C++ member cannot take the name of its type)
+    B18. types that declare a constructor get `T() = default;` (C# structs always have the parameterless one; `new()` uses it)
+    """
+    text = text.replace("\r\n", "\n").replace("\t", "    ")
+    text = "\n".join(ln for ln in text.split("\n") if not re.match(r"\s*using\s+[\w.]+;", ln))           # B1
+    text = text.replace("[System.Serializable]", "")                                                       # B1
+    text = re.sub(r"namespace\s+(\w+)\.(\w+)", r"namespace \1::\2", text)                                     # B1
+    for pat in BVH_CUT:                                                                                    # B2
+        a, b = _block(text, pat)
+        text = text[:a] + text[b:]
+    text = re.sub(r"\n\s*// ---- Traversal ---\s*\n", "\n", text)
+    moved = []
+    for name in BVH_TYPES:                                                                                 # B3
+        a, b = _block(text, r"public (?:readonly )?(?:struct|class) %s\b" % name)
+        blk = text[a:b]
+        text = text[:a] + text[b:]
+        if re.search(r"\b%s\(" % name, blk):                                                              # B18
+            i = blk.index("{") + 1
+            blk = blk[:i] + "\n            %s() = default;" % name + blk[i:]
+        if name == "BuildStats":                                                                           # B17
+            blk = blk.replace("public Quality Quality;", "public Quality Quality_;").replace("this.Quality = quality;", "this.Quality_ = quality;")
+        moved.append(blk + ";")
+    a, b = _block(text, r"public enum Quality\b")
+    text = text[:b] + ";\n\n" + "\n\n".join(moved) + "\n" + text[b:]
+    a, b = _block(text, r"public class BVH\b")
+    text = text[:b] + ";" + text[b:]
+    text = re.sub(r"\b(public|readonly|private|override)\s+", "", text)                                    # B4
+    text = re.sub(r"\bclass\b", "struct", text)
+    text = re.sub(r"\benum\b", "enum class", text)
+    text = re.sub(r"\bnew (\w+)\[([^\]]+)\]", r"CsArray<\1>(\2)", text)                                    # B5
+    text = re.sub(r"\b(\w+)\[\]", r"CsArray<\1>", text)
+    text = re.sub(r"\b(\w+) (\w+) = new\(", r"\1 \2 = \1(", text)                                          # B6
+    text = re.sub(r"= new\(\);", "= {};", text)
+    text = re.sub(r"\bnew (\w+)\(", r"\1(", text)
+    text = re.sub(r"\bref (\w+) (\w+) = ref ", r"\1& \2 = ", text)                                         # B7
+    text = text.replace("System.Diagnostics.Stopwatch.StartNew()", "Stopwatch::StartNew()")               # B8
+    text = re.sub(r"\bvar\b", "auto", text)
+    for cs, cpp in (("float.MaxValue", "CS_FLOAT_MAX"), ("float.MinValue", "CS_FLOAT_MIN"),                # B9
+                    ("float.PositiveInfinity", "CS_FLOAT_POSITIVE_INFINITY"), ("int.MaxValue", "CS_INT_MAX")):
+        text = text.replace(cs, cpp)
+    text = re.sub(r"(?<![\w.])(\d+)f\b", r"\1.0f", text)                                                   # B10
+    text = re.sub(r"\(int axis, float pos, float cost\) (\w+)\(", r"std::tuple<int, float, float> \1(", text)   # B11
+    text = re.sub(r"\breturn \(([^;]*,[^;]*,[^;]*)\);", r"return std::make_tuple(\1);", text)
+    text = re.sub(r"\(int (\w+), float (\w+), float (\w+)\) = ", r"auto [\1, \2, \3] = ", text)
+    text = re.sub(r"(\w+) switch\s*\{\s*0 => ([^,]+),\s*1 => ([^,]+),\s*_ => ([^}]+?)\s*\};",                 # B12
+                  r"(\1 == 0 ? \2 : \1 == 1 ? \3 : \4);", text)
+    text = re.sub(r"\b(Mathf|Math|Quality)\.", r"\1::", text)                                              # B13
+    text = re.sub(r"\bArray\.Resize\(ref ", "Array::Resize(", text)
+    text = re.sub(r"\bthis\.", "this->", text)                                                             # B14
+    text = re.sub(r"\bint NodeCount => Index;", "int NodeCount() const { return Index; }", text)           # B15
+    text = re.sub(r"\.NodeCount\b(?!\s*\()", ".NodeCount()", text)
+    text = re.sub(r"^(\s*)(int|float) (\w+);", r"\1\2 \3{};", text, flags=re.M)                              # B16
+    if re.search(r"=>|\bswitch\s*\{|\bnew\b|\bref\b|\$\"", text):
+        raise SystemExit("BVH.cs: a C# construct survived the rewrites — the reference changed, review oracle/make_ref.py")
+    return text
+
+
+def bvh_translation_unit():
+    with open(BVH_SOURCE, "r", encoding="utf-8-sig") as f:
+        body = rewrite_bvh(f.read())
+    return ('#include "%s"\n/* ---- BVH.cs ---- */\n%s\n#include "%s"\n'
+            % (os.path.join(HERE, "ref_bvh_compat.h"), body, os.path.join(HERE, "ref_bvh_driver.h")))
+
+
+def bvh_available():
+    return os.path.exists(BVH_SOURCE)
+
+
+def build_bvh(emit=None, quiet=False):
+    if not bvh_available():
+        raise FileNotFoundError("reference BVH.cs not found: %s" % BVH_SOURCE)
+    tu = bvh_translation_unit()
+    if emit:
+        if os.path.abspath(emit).startswith(os.path.dirname(HERE) + os.sep):
+            raise SystemExit("--emit inside the repository would copy reference text into it: choose a path outside")
+        with open(emit, "w") as f:
+            f.write(tu)
+    os.makedirs(OUT_DIR, exist_ok=True)
+    out = os.path.join(OUT_DIR, "libref_bvh.so")
+    cmd = [os.environ.get("CXX", "g++")] + CXXFLAGS + ["-I", HERE, "-shared", "-o", out, "-x", "c++", "-"]
+    subprocess.run(cmd, input=tu.encode(), check=True, stdout=subprocess.DEVNULL if quiet else None)
+    return out
+
+
 def available():
     return all(os.path.exists(os.path.join(SHADER_DIR, s)) for s in SOURCES)
 
@@ -126,10 +261,16 @@ if __name__ == "__main__":
     ap.add_argument("--ieee", action="store_true")
     ap.add_argument("--both", action="store_true")
     ap.add_argument("--emit")
+    ap.add_argument("--bvh", action="store_true", help="build oracle/_ref/libref_bvh.so (BVH.cs) instead of the shader library")
     ap.add_argument("--if-available", action="store_true", help="exit 0 quietly when /root/reference is absent (GPU box)")
     a = ap.parse_args()
     if a.if_available and not available():
         print("make_ref: %s absent — keeping whatever oracle/_ref/ holds" % SHADER_DIR)
         sys.exit(0)
+    if a.bvh:
+        print("built", build_bvh(emit=a.emit))
+        sys.exit(0)
     for ieee in ((False, True) if a.both else (a.ieee,)):
         print("built", build(ieee=ieee, emit=a.emit))
+    if a.both and bvh_available():
+        print("built", build_bvh())

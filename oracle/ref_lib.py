@@ -80,3 +80,55 @@ def load(pkg, variant=""):
             return t
 
     return RefApi()
+
+
+# ---- the reference's BVH builder (BVH.cs compiled as C++): oracle/_ref/libref_bvh.so ---------------------------------
+def bvh_lib_path():
+    return os.path.join(_HERE, "_ref", "libref_bvh.so")
+
+
+def build_bvh_lib(force=False):
+    path = bvh_lib_path()
+    if make_ref.bvh_available():
+        deps = [os.path.join(_HERE, f) for f in ("make_ref.py", "ref_bvh_compat.h", "ref_bvh_driver.h", "../include/rt_abi.h")] + [make_ref.BVH_SOURCE]
+        if force or not os.path.exists(path) or any(os.path.getmtime(d) > os.path.getmtime(path) for d in deps):
+            make_ref.build_bvh(quiet=True)
+    return path if os.path.exists(path) else None
+
+
+def load_bvh(pkg):
+    """build_bvh_arrays(verts, normals, indices, quality) of the reference's own BVH.cs text, or None when the library cannot be had."""
+    path = build_bvh_lib()
+    if path is None:
+        return None
+    import numpy as np
+    abi = pkg.abi
+
+    class RefBvh:
+        def __init__(self):
+            self.path = path
+            self.lib = C.CDLL(path, mode=getattr(os, "RTLD_LOCAL", 0) | getattr(os, "RTLD_NOW", 2))
+            self.lib.ref_bvh_build.restype = C.c_int
+            self.lib.ref_bvh_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int),
+                                               C.c_void_p, C.POINTER(abi.RtBvhStats)]
+            self.lib.ref_bvh_version.restype = C.c_char_p
+
+        def version(self):
+            return self.lib.ref_bvh_version()
+
+        def build_bvh_arrays(self, verts, normals, indices, quality=abi.BVH_QUALITY_HIGH):
+            verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+            normals = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+            indices = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1)
+            ntri = len(indices) // 3
+            nodes = np.zeros(2 * max(1, ntri), dtype=abi.node_dtype)
+            tris = np.zeros(ntri, dtype=abi.triangle_dtype)
+            n_nodes = C.c_int(0)
+            stats = abi.RtBvhStats()
+            rc = self.lib.ref_bvh_build(verts.ctypes.data, normals.ctypes.data, len(verts), indices.ctypes.data, len(indices), int(quality),
+                                        nodes.ctypes.data, C.byref(n_nodes), tris.ctypes.data, C.byref(stats))
+            if rc != abi.RT_OK:
+                raise abi.RtError(rc, "ref_bvh_build failed")
+            return nodes[: n_nodes.value].copy(), tris, stats.as_dict()
+
+    return RefBvh()

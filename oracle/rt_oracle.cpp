@@ -21,8 +21,11 @@
  * is include/rt_math.h itself (what '/', normalize, pow, ... evaluate to in fp32 — left to the compiler by HLSL);
  * tests/test_contract_bracket.py brackets it.  Also pinned by hand-derived known-answer tests per function
  * (tests/test_oracle_kat.py), BVH == brute-force property tests, furnace tests and the golden fixtures (tests/golden/).
- * The sphere buffer (extension S1) and BVH.cs (C#) are outside the shader text: RaySphere is compared at function
- * level, the BVH builder stays a restatement.
+ * The sphere buffer (extension S1) is outside the shader text: RaySphere is compared at function level.  BVH.cs is C#, and is
+ * pinned the same way: `oracle/make_ref.py --bvh` compiles BVH.cs:26-318 and its nested types AS THEY STAND (eighteen listed
+ * syntactic rewrites; oracle/ref_bvh_compat.h supplies Vector3, C# arrays, Mathf and Math) into oracle/_ref/libref_bvh.so, and
+ * tests/test_ref_pin.py demands that the builder below — and the product's host builder on one and five threads — emits the same
+ * nodes, triangle order and BuildStats byte for byte on every mesh class; tests/test_gpu_ref_pin.py does it for the GPU builder.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
  * this library.  The product (libraytrace_hip.so) never links or calls it.

@@ -62,3 +62,29 @@ def test_hip_equals_the_compiled_reference_text(pkg, api, orc, ref, case):
     assert c0["segments"] == cr["segments"] == c1["segments"]
     assert c1["triTests"] == cr["triTests"], (name, c1, cr)        # stats[0], RC:254
     assert c1["innerSteps"] == cr["innerSteps"], (name, c1, cr)    # stats[1] / 2, RC:271
+
+
+def test_gpu_bvh_builder_equals_the_compiled_reference_bvh_text(pkg, api):
+    """rt_build_bvh_gpu and the forest of rt_build_bvh_gpu_batch against BVH.cs itself (oracle/_ref/libref_bvh.so: the reference's C#
+    text compiled as C++): nodes, triangle order and BuildStats byte for byte — no restatement in between."""
+    ref_bvh = ref_lib.load_bvh(pkg)
+    if ref_bvh is None:
+        pytest.skip("oracle/_ref/libref_bvh.so did not travel with the snapshot")
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_bvh
+    meshes = test_bvh.mesh_cases(pkg) + [pkg.meshes.icosphere(5, 1.0, 2), pkg.meshes.icosphere(6, 1.0, 4)]
+
+    def same(a, b):
+        sa, sb = dict(a[2]), dict(b[2])
+        sa.pop("timeMs"), sb.pop("timeMs")
+        return a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes() and sa == sb
+
+    for quality in (0, 1, 2):
+        refs = [ref_bvh.build_bvh_arrays(m.vertices, m.normals, m.triangles, quality) for m in meshes]
+        for m, r in zip(meshes, refs):
+            assert same(api.build_bvh_arrays_gpu(m.vertices, m.normals, m.triangles, quality), r), (m.name, quality)
+        nd, tr, per = api.build_bvh_arrays_gpu_batch([(m.vertices, m.normals, m.triangles) for m in meshes], quality)
+        for m, r, (noff, toff, stats) in zip(meshes, refs, per):
+            assert same((nd[noff:noff + len(r[0])], tr[toff:toff + len(r[1])], stats), r), ("batch", m.name, quality)
+    api.build_bvh_gpu_release()

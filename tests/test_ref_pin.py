@@ -297,3 +297,122 @@ def test_rewrites_are_only_the_listed_syntactic_ones():
         o = re.sub(r"\s*:\s*SV_DispatchThreadID", "", o)
         o = re.sub(r"^const\s+(uint2|bool)\s+(\w+);", r"\1 \2;", o, flags=re.M)
         assert t.split() == o.split(), name
+
+
+# ------------------------------------------------------------------------------------------------ BVH.cs
+@pytest.fixture(scope="module")
+def ref_bvh(pkg):
+    lib = ref_lib.load_bvh(pkg)
+    if lib is None:
+        pytest.skip("oracle/_ref/libref_bvh.so absent and no reference checkout to build it from")
+    return lib
+
+
+def _bvh_meshes(pkg):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_bvh
+    return test_bvh.mesh_cases(pkg) + [pkg.meshes.icosphere(4, 1.0, 7), pkg.meshes.icosphere(5, 1.0, 2), pkg.meshes.rounded_cube(12)]
+
+
+def _same_build(a, b):
+    sa, sb = dict(a[2]), dict(b[2])
+    sa.pop("timeMs"), sb.pop("timeMs")
+    return a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes() and sa == sb
+
+
+@pytest.mark.parametrize("quality", [0, 1, 2])
+def test_bvh_builders_equal_the_compiled_reference_bvh_text(pkg, api, orc, ref_bvh, quality):
+    """BVH.cs:26-318 itself (oracle/make_ref.py --bvh: the C# text compiled as C++ after the listed syntactic rewrites) against the
+    oracle's restatement and the product's host builder (one thread and five): nodes, triangle order and BuildStats byte for byte,
+    on every mesh class incl. the degenerate ones (identical triangles, flat, point: NaN in CeilToInt)."""
+    assert b"BVH.cs" in ref_bvh.version()
+    for m in _bvh_meshes(pkg):
+        r = ref_bvh.build_bvh_arrays(m.vertices, m.normals, m.triangles, quality)
+        assert _same_build(orc.build_bvh_arrays(m.vertices, m.normals, m.triangles, quality), r), ("oracle", m.name)
+        assert _same_build(api.build_bvh_arrays(m.vertices, m.normals, m.triangles, quality), r), ("product", m.name)
+        for threads in (1, 5):
+            assert _same_build(api.build_bvh_arrays_mt(m.vertices, m.normals, m.triangles, quality, threads), r), ("product mt", threads, m.name)
+
+
+def test_bvh_benchmark_mesh_and_refusals_equal_the_reference_bvh_text(pkg, api, orc, ref_bvh):
+    """The 81,920-triangle mesh of BASELINE configs 4 and 5; an empty mesh; and input whose split costs overflow (BVH.cs grows a chain of
+    empty leaves there: all three refuse it with RT_ERR_SCENE instead of emitting a tree the shader cannot walk, RC:246)."""
+    m = pkg.meshes.icosphere(6, 1.0, 4)
+    assert m.triangle_count == 81920
+    r = ref_bvh.build_bvh_arrays(m.vertices, m.normals, m.triangles, 1)
+    assert _same_build(api.build_bvh_arrays(m.vertices, m.normals, m.triangles, 1), r)
+    assert _same_build(orc.build_bvh_arrays(m.vertices, m.normals, m.triangles, 1), r)
+    assert r[2]["leafNodeCount"] == (len(r[0]) + 1) // 2 and r[2]["triangleCount"] == 81920
+    empty = (np.zeros((3, 3), np.float32), np.zeros((3, 3), np.float32), np.zeros(0, np.int32))
+    assert _same_build(api.build_bvh_arrays(*empty, 1), ref_bvh.build_bvh_arrays(*empty, 1))
+    assert _same_build(orc.build_bvh_arrays(*empty, 1), ref_bvh.build_bvh_arrays(*empty, 1))
+    rng = np.random.default_rng(3)
+    v = (rng.uniform(-1, 1, (64, 3)) * 3e19).astype(np.float32)      # extents ~1e20: area * count overflows to inf, inf < inf is false
+    idx = rng.integers(0, 64, 3 * 40).astype(np.int32)
+    outcomes = []
+    for lib in (ref_bvh, orc, api):
+        try:
+            outcomes.append(("ok", lib.build_bvh_arrays(v, np.zeros_like(v), idx, 1)))
+        except pkg.abi.RtError as e:
+            outcomes.append(("refused", e.status))
+    assert outcomes[0][0] == outcomes[1][0] == outcomes[2][0]
+    if outcomes[0][0] == "ok":
+        assert _same_build(outcomes[1][1], outcomes[0][1]) and _same_build(outcomes[2][1], outcomes[0][1])
+    else:
+        assert outcomes[0][1] == outcomes[1][1] == outcomes[2][1] == pkg.abi.RT_ERR_SCENE
+    bad = idx.copy()
+    bad[5] = 64
+    for lib in (ref_bvh, orc, api):
+        with pytest.raises(pkg.abi.RtError) as e:
+            lib.build_bvh_arrays(v, np.zeros_like(v), bad, 1)
+        assert e.value.status == pkg.abi.RT_ERR_INVALID_ARG
+
+
+@pytest.mark.skipif(not ref_lib.make_ref.bvh_available(), reason="needs the reference checkout")
+def test_bvh_rewrites_are_only_the_listed_syntactic_ones():
+    """Undo the rewrites of make_ref.rewrite_bvh() on its output and compare with BVH.cs line by line (as a multiset: B3 moves the
+    nested types in front of their first use).  What is not undone is applied to the original instead and is named here: the cut
+    members (B2), the dropped modifiers (B4), `class` -> `struct`, and the switch expressions (B12)."""
+    mk = ref_lib.make_ref
+    with open(mk.BVH_SOURCE, encoding="utf-8-sig") as f:
+        original = f.read().replace("\r\n", "\n").replace("\t", "    ")
+    t = mk.rewrite_bvh(original)
+    t = re.sub(r"^\s*\w+\(\) = default;\n", "", t, flags=re.M)                                       # B18
+    t = t.replace("Quality Quality_;", "Quality Quality;").replace("this->Quality_ = quality;", "this->Quality = quality;")   # B17
+    t = re.sub(r"^(\s*)(int|float) (\w+)\{\};", r"\1\2 \3;", t, flags=re.M)                            # B16
+    t = t.replace("int NodeCount() const { return Index; }", "int NodeCount => Index;").replace(".NodeCount()", ".NodeCount")   # B15
+    t = t.replace("this->", "this.")                                                                 # B14
+    t = t.replace("Array::Resize(", "Array.Resize(ref ")                                             # B13
+    t = re.sub(r"\b(Mathf|Math|Quality)::", r"\1.", t)
+    t = re.sub(r"return std::make_tuple\(([^;]*)\);", r"return (\1);", t)                            # B11
+    t = t.replace("std::tuple<int, float, float> ", "(int axis, float pos, float cost) ")
+    t = re.sub(r"auto \[(\w+), (\w+), (\w+)\] = ", r"(int \1, float \2, float \3) = ", t)
+    t = re.sub(r"(?<![\w.])(\d+)\.0f\b", r"\1f", t)                                                   # B10
+    for cs, cpp in (("float.MaxValue", "CS_FLOAT_MAX"), ("float.MinValue", "CS_FLOAT_MIN"),          # B9
+                    ("float.PositiveInfinity", "CS_FLOAT_POSITIVE_INFINITY"), ("int.MaxValue", "CS_INT_MAX")):
+        t = t.replace(cpp, cs)
+    t = re.sub(r"\bauto\b", "var", t)                                                                # B8
+    t = t.replace("Stopwatch::StartNew()", "System.Diagnostics.Stopwatch.StartNew()")
+    t = re.sub(r"\b(\w+)& (\w+) = ", r"ref \1 \2 = ref ", t)                                          # B7
+    t = re.sub(r"= \{\};", "= new();", t)                                                            # B6
+    t = re.sub(r"\b(\w+) (\w+) = \1\(", r"\1 \2 = new(", t)
+    t = re.sub(r"CsArray<(\w+)>\(([^)]+)\)", r"new \1[\2]", t)                                        # B5
+    t = re.sub(r"CsArray<(\w+)>", r"\1[]", t)
+    t = re.sub(r"\benum class\b", "enum", t)                                                         # B4
+    t = re.sub(r"\}\s*;", "}", t)                                                                    # B3
+    t = re.sub(r"namespace (\w+)::(\w+)", r"namespace \1.\2", t)                                      # B1
+
+    o = "\n".join(ln for ln in original.split("\n") if not re.match(r"\s*using\s+[\w.]+;", ln)).replace("[System.Serializable]", "")
+    for pat in mk.BVH_CUT:
+        a, b = mk._block(o, pat)
+        o = o[:a] + o[b:]
+    o = re.sub(r"\n\s*// ---- Traversal ---\s*\n", "\n", o)
+    o = re.sub(r"\b(public|readonly|private|override)\s+", "", o)
+    o = re.sub(r"\bclass\b", "struct", o)
+    o = re.sub(r"(\w+) switch\s*\{\s*0 => ([^,]+),\s*1 => ([^,]+),\s*_ => ([^}]+?)\s*\};", r"(\1 == 0 ? \2 : \1 == 1 ? \3 : \4);", o)
+    o = re.sub(r"\bnew (\w+)\(", r"\1(", o)            # `new T(args)` -> `T(args)` (B6) cannot be told from a call afterwards: applied here
+    o = re.sub(r"\}\s*;", "}", o)
+
+    def lines(s):
+        return sorted(" ".join(ln.split()) for ln in s.split("\n") if ln.strip())
+    assert lines(t) == lines(o)
