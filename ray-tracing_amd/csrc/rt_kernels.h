@@ -640,6 +640,19 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
                 float aMin[3] = {q0.x, q0.y, q0.z}, aMax[3] = {q0.w, q1.x, q1.y};
                 float bMin[3] = {q1.z, q1.w, q2.x}, bMax[3] = {q2.y, q2.z, q2.w};
                 uint32_t codeA = __float_as_uint(q3.x), codeB = __float_as_uint(q3.y);
+#ifdef RT_CHILD_PREFETCH
+                /* EXPERIMENT (make child-prefetch): touch one dword of each child's record (the pair of an inner child, the first
+                 * triangle of a leaf child) as soon as the codes are known, so that the line is on its way while the box tests run */
+                {
+                    const uint32_t offA = (codeA & RT_CODE_LEAF) ? (uint32_t)(t.triBase + (int)(codeA & RT_CODE_MAX_INLINE_START)) * (uint32_t)sizeof(DTri) : codeA << 6;
+                    const uint32_t offB = (codeB & RT_CODE_LEAF) ? (uint32_t)(t.triBase + (int)(codeB & RT_CODE_MAX_INLINE_START)) * (uint32_t)sizeof(DTri) : codeB << 6;
+                    const char* baseA = (codeA & RT_CODE_LEAF) ? reinterpret_cast<const char*>(tris) : reinterpret_cast<const char*>(pairs);
+                    const char* baseB = (codeB & RT_CODE_LEAF) ? reinterpret_cast<const char*>(tris) : reinterpret_cast<const char*>(pairs);
+                    uint32_t ta, tb;
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(ta) : "v"(baseA + offA) : "memory");
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(tb) : "v"(baseB + offB) : "memory");
+                }
+#endif
                 float dstA = box_dst(t.lpos, t.linv, aMin, aMax);
                 float dstB = box_dst(t.lpos, t.linv, bMin, bMax);
                 bool isNearestA = dstA <= dstB;
