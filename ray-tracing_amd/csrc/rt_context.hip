@@ -23,6 +23,7 @@
 #include <atomic>
 #include <chrono>
 #include <thread>
+#include <unordered_map>
 
 #ifdef RT_WG_EXPERIMENT /* make wg: the queued stages with the parked chains in a workgroup-wide LDS pool (rt_kernels_wg.h) */
 #define RT_QUEUED_EXPERIMENT
@@ -1028,11 +1029,17 @@ static int prepare_scene(RtContext* ctx, const RtModel* models, int n_models, co
     struct MeshJob { int nodeOffset, triOffset, firstModel; size_t segStart = 0; SceneBuilder sb; uint32_t code = 0; int height = 0; long long leafEnd = 0; bool ok = false; };
     std::vector<MeshJob> jobs;
     std::vector<int> jobOfModel(n_models, 0);
-    for (int i = 0; i < n_models; i++) {
-        int j = 0;
-        while (j < (int)jobs.size() && jobs[j].nodeOffset != models[i].nodeOffset) j++;
-        if (j == (int)jobs.size()) { jobs.emplace_back(); jobs[j].nodeOffset = models[i].nodeOffset; jobs[j].triOffset = models[i].triOffset; jobs[j].firstModel = i; }
-        jobOfModel[i] = j;
+    {
+        std::unordered_map<int, int> jobOfRoot; /* (a scene of 10^5 models with a mesh each must not pay 10^10 comparisons here) */
+        for (int i = 0; i < n_models && jobs.size() <= 256; i++) { /* more than 256 meshes: the sequential walk below, no jobs needed */
+            auto it = jobOfRoot.find(models[i].nodeOffset);
+            if (it == jobOfRoot.end()) {
+                it = jobOfRoot.emplace(models[i].nodeOffset, (int)jobs.size()).first;
+                jobs.emplace_back();
+                jobs.back().nodeOffset = models[i].nodeOffset; jobs.back().triOffset = models[i].triOffset; jobs.back().firstModel = i;
+            }
+            jobOfModel[i] = it->second;
+        }
     }
     bool merged = false;
     size_t nPairs = 0;
