@@ -619,7 +619,7 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
                  * 64-bit shift and add of a full pointer (two slow-class VALU instructions per step on gfx950) become one fast
                  * 32-bit shift; rt_upload_scene refuses scenes with 2^26 pairs or more */
                 const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pairs) + (uint32_t)(t.cur << 6));
-                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3]; /* (loading only the 8 bytes of q3 that are used changes nothing: 9.9) */
 #else
                 /* EXPERIMENT kept reproducible (make lds-fetch; profiles/r02_lds_node_fetch.txt): the north_star's
                  * "BVH nodes staged through LDS" as the hardware offers it — the node's four 16-B quarters go
