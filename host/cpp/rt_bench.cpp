@@ -3,7 +3,7 @@
 // C++ RayComputeManager mirror, renders N frames, prints one JSON line, optionally dumps the
 // uploaded buffers + the accumulation image so tests can replay them through the CPU oracle.
 //
-//   rt_bench --config 2|3 [--width W --height H] [--frames N] [--warmup K] [--seed S] [--dump prefix] [--scene-only]
+//   rt_bench --config 2|3 [--width W --height H] [--frames N] [--warmup K] [--seed S] [--dump prefix] [--scene-only] [--bvh-gpu]
 //            [--devices 0,1,...]   several GPUs from this one process: rt_create_multi (cyclic 8-row strips per
 //                                  device, gather at readback); a device id may repeat (virtual shards on one GPU)
 #include <chrono>
@@ -29,7 +29,7 @@ int main(int argc, char** argv)
     int config = 2, width = 0, height = 0, frames = 10, warmup = 1, seed = 1;
     std::string dumpPrefix;
     std::vector<int> devices;
-    bool sceneOnly = false;
+    bool sceneOnly = false, bvhGpu = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() { return i + 1 < argc ? argv[++i] : "0"; };
@@ -41,6 +41,7 @@ int main(int argc, char** argv)
         else if (a == "--seed") seed = atoi(val());
         else if (a == "--dump") dumpPrefix = val();
         else if (a == "--scene-only") sceneOnly = true;
+        else if (a == "--bvh-gpu") bvhGpu = true; // every distinct mesh's BVH in one rt_build_bvh_gpu_batch call
         else if (a == "--devices") {
             std::string list = val();
             for (size_t p = 0; p <= list.size();) {
@@ -60,6 +61,7 @@ int main(int argc, char** argv)
         if (config == 2) BuildConfig2(mgr);
         else if (config == 3) BuildConfig3(mgr);
         else { fprintf(stderr, "config must be 2 or 3\n"); return 2; }
+        mgr.bvhOnGpu = bvhGpu;
 
         std::vector<float> multiImage;
         if (sceneOnly) { // host logic only (no GPU): build the buffers the dispatcher would upload

@@ -245,6 +245,31 @@ void RayComputeManager::CreateAllMeshData() // RCM:206-236
     triangles.clear();
     nodes.clear();
     std::map<const Mesh*, std::pair<int, int>> meshLookup; // mesh -> (nodeOffset, triOffset)
+    if (bvhOnGpu) { // the distinct meshes in first-use order, all in one call: nodes / triangles come back concatenated (RCM:214-223)
+        std::vector<const Mesh*> distinct;
+        for (const Model& model : models)
+            if (!meshLookup.count(model.mesh.get())) { meshLookup[model.mesh.get()] = {0, 0}; distinct.push_back(model.mesh.get()); }
+        const int K = (int)distinct.size();
+        std::vector<const float*> v(K), nrm(K);
+        std::vector<const int32_t*> idx(K);
+        std::vector<int> nv(K), ni(K), nn(K, 0), nodeOff(K, 0), triOff(K, 0);
+        size_t nodeCap = 0, triCap = 0;
+        for (int k = 0; k < K; k++) {
+            v[k] = distinct[k]->vertices.data(); nrm[k] = distinct[k]->normals.data(); idx[k] = distinct[k]->triangles.data();
+            nv[k] = (int)distinct[k]->vertices.size() / 3; ni[k] = (int)distinct[k]->triangles.size();
+            nodeCap += 2 * (size_t)std::max(1, distinct[k]->triangleCount());
+            triCap += (size_t)distinct[k]->triangleCount();
+        }
+        nodes.resize(nodeCap);
+        triangles.resize(triCap);
+        if (K) {
+            int rc = rt_build_bvh_gpu_batch(bvhDevice, K, v.data(), nrm.data(), nv.data(), idx.data(), ni.data(), bvhQuality, nodes.data(), nn.data(),
+                                            nodeOff.data(), triangles.data(), triOff.data(), nullptr);
+            if (rc != RT_OK) throw RtError(rc, "rt_build_bvh_gpu_batch failed");
+            nodes.resize((size_t)nodeOff[K - 1] + nn[K - 1]);
+        }
+        for (int k = 0; k < K; k++) meshLookup[distinct[k]] = {nodeOff[k], triOff[k]};
+    }
     for (const Model& model : models) {
         const Mesh* mesh = model.mesh.get();
         if (!meshLookup.count(mesh)) { // first time this mesh is seen: build its BVH (RCM:214-223)

@@ -92,6 +92,8 @@ class RayComputeManager {
     bool rayTracingEnabled = true;
     bool accumulate = true;
     int bvhQuality = RT_BVH_QUALITY_HIGH;
+    bool bvhOnGpu = false;                      // build every distinct mesh's BVH in one rt_build_bvh_gpu_batch call (same bytes)
+    int bvhDevice = 0;
     int maxBounceCount = 4;
     int numRaysPerPixel = 1;
     float defocusStrength = 0;

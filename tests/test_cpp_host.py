@@ -56,6 +56,17 @@ def test_cpp_host_fails_loudly_without_gpu(bench):
 
 
 @pytest.mark.gpu
+def test_cpp_host_gpu_bvh_batch_gives_the_same_buffers(pkg, bench, tmp_path):
+    """--bvh-gpu: CreateAllMeshData through one rt_build_bvh_gpu_batch call (the scene's meshes as one forest) — the buffers the
+    compiled host would upload are byte for byte the ones its host-builder path makes."""
+    a, b = str(tmp_path / "host"), str(tmp_path / "gpu")
+    subprocess.check_call([bench, "--config", "3", "--width", "64", "--height", "36", "--scene-only", "--dump", a])
+    subprocess.check_call([bench, "--config", "3", "--width", "64", "--height", "36", "--scene-only", "--bvh-gpu", "--dump", b])
+    for x, y in zip(_load(pkg, a)[:4], _load(pkg, b)[:4]):
+        assert x.tobytes() == y.tobytes()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [2, 3])
 def test_cpp_host_render_equals_oracle(pkg, orc, bench, tmp_path, cfg):
     prefix = str(tmp_path / f"g{cfg}")
