@@ -132,8 +132,13 @@ __device__ __forceinline__ void phase_mark(Stats& st, int ph)
 __device__ __forceinline__ float rand_normal(uint32_t* state)
 {
     float theta = 2 * 3.1415926f * rt_random_value(state);
+#ifdef RT_FAST_TRANS_CEILING /* measurement only (NOT bit-exact): what hardware log / cos would buy — the ceiling of any cheaper contract */
+    float rho = __builtin_sqrtf(-2 * __logf(rt_random_value(state)));
+    return rho * __cosf(theta);
+#else
     float rho = rt_sqrt(-2 * rt_log(rt_random_value(state)));
     return rho * rt_cos(theta);
+#endif
 }
 __device__ __forceinline__ rt_f3 rand_direction(uint32_t* state)
 {
