@@ -270,7 +270,8 @@ class RayComputeManager:
                 if id(model.Mesh) not in meshLookup:
                     meshLookup[id(model.Mesh)] = len(uniq)
                     uniq.append(model.Mesh)
-            nd, tr, per = self.api.build_bvh_arrays_gpu_batch([(m.vertices, m.normals, m.triangles) for m in uniq], self.bvhQuality)
+            nd, tr, per = self.api.build_bvh_arrays_gpu_batch([(m.vertices, m.normals, m.triangles) for m in uniq], self.bvhQuality,
+                                                              getattr(self, "bvhDevice", 0))
             for m, (_, _, stats) in zip(uniq, per):
                 self.bvhStats[m.name] = stats
             for i, model in enumerate(models):
@@ -285,9 +286,10 @@ class RayComputeManager:
                 meshLookup[key] = (n_nodes, n_tris)
                 # the tree is the reference's whichever builder makes it (byte-identical): the multi-threaded host
                 # builder, or — bvhOnGpu — rt_build_bvh_gpu
-                build = self.api.build_bvh_arrays_gpu if getattr(self, "bvhOnGpu", False) and hasattr(self.api, "build_bvh_arrays_gpu") \
-                    else self.api.build_bvh_arrays
-                nd, tr, stats = build(model.Mesh.vertices, model.Mesh.normals, model.Mesh.triangles, self.bvhQuality)
+                on_gpu = getattr(self, "bvhOnGpu", False) and hasattr(self.api, "build_bvh_arrays_gpu")
+                build = self.api.build_bvh_arrays_gpu if on_gpu else self.api.build_bvh_arrays
+                extra = (getattr(self, "bvhDevice", 0),) if on_gpu else ()
+                nd, tr, stats = build(model.Mesh.vertices, model.Mesh.normals, model.Mesh.triangles, self.bvhQuality, *extra)
                 self.bvhStats[model.Mesh.name] = stats
                 tris.append(tr)
                 nodes.append(nd)

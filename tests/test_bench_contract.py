@@ -109,6 +109,8 @@ def test_round4_roofline_is_self_consistent(path):
     assert sec["void"] is (sec["frac_of_peak"] > 1.0) and math.isclose(sec["frac_of_peak"], sec["GBps"] / 8000.0, rel_tol=1e-9)
     assert r["fetch_size_factor"]["factor"] == 2.0 and "r04_fetch_size_calibration" in r["fetch_size_factor"]["calibration"]
     assert os.path.exists(os.path.join(ROOT, "profiles", "r04_fetch_size_calibration.txt")) and os.path.exists(os.path.join(ROOT, "profiles", "isa_mix.json"))
+    if "scene_load" in d:      # lines of the final build: the scene set-up (GPU BVH forest + upload) is reported beside the timed region
+        assert d["scene_load"]["ms"] > 0 and d["scene_load"]["bvh_build_ms"] >= 0 and "outside the timed region" in d["scene_load"]["what"]
 
 
 @pytest.mark.parametrize("path", MULTI, ids=[os.path.basename(p) for p in MULTI])
