@@ -167,6 +167,11 @@ struct RtContext {
     hipEvent_t evAccWriter[2] = {nullptr, nullptr};
     bool accWriterPending[2] = {false, false};
     bool accWriterFull[2] = {false, false}; /* that kernel touches every pixel (an accumulate kernel, a one-part frame); false = one half of a two-part frame */
+    /* the last FULL writer of a stream is tracked on its own: a half kernel launched behind it on the same stream re-records
+     * evAccWriter[s] with full = false, and the other stream's half of that very frame would then no longer wait for the full
+     * writer (rt_render_frames(17): 16 fused frames + 1 two-part frame; found by tools/soak.py, round 4) */
+    hipEvent_t evAccFull[2] = {nullptr, nullptr};
+    bool accFullPending[2] = {false, false};
     int lastLaunched = 0;            /* frames the last launch_frames call really enqueued (flush_pending rolls back the rest) */
     void* dDisplay = nullptr;  /* scratch of the display pass, kept between calls (grows on demand) */
     size_t displayBytes = 0;
@@ -203,6 +208,7 @@ static hipStream_t joined(RtContext* ctx)
         hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0);
         ctx->sideDirty = false;
         ctx->accWriterPending[1] = false; /* whatever the side stream adds to the accumulation buffer now precedes the main stream's next kernel */
+        ctx->accFullPending[1] = false;
     }
     ctx->needFork = true;
     return ctx->stream;
@@ -325,6 +331,8 @@ int rt_create(int device_id, RtContext** out)
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evAccWriter[0], hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evAccWriter[1], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evAccFull[0], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evAccFull[1], hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evSort, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evOrderRetire[0], hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evOrderRetire[1], hipEventDisableTiming));
@@ -390,6 +398,7 @@ void rt_destroy(RtContext* ctx)
     hipFree(ctx->dStaging[0]);
     hipFree(ctx->dStaging[1]);
     for (int i = 0; i < 2; i++) if (ctx->evAccWriter[i]) hipEventDestroy(ctx->evAccWriter[i]);
+    for (int i = 0; i < 2; i++) if (ctx->evAccFull[i]) hipEventDestroy(ctx->evAccFull[i]);
     hipFree(ctx->dPxCold);
     hipFree(ctx->dQRecords);
     hipFree(ctx->dWgRecords);
@@ -1722,6 +1731,10 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
      * same set of pixels, and a sort joins the streams) */
     auto order_acc_writer = [&](int s, bool full) -> int {
         hipStream_t st = s ? ctx->sideStream : ctx->stream;
+        if (ctx->accFullPending[1 - s]) { /* the other stream's last whole-image writer: once waited for, everything later on this stream follows it */
+            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->evAccFull[1 - s], 0));
+            ctx->accFullPending[1 - s] = false;
+        }
         if (ctx->accWriterPending[1 - s] && (full || ctx->accWriterFull[1 - s])) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->evAccWriter[1 - s], 0));
         return RT_OK;
     };
@@ -1729,6 +1742,10 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         HIP_TRY(ctx, hipEventRecord(ctx->evAccWriter[s], s ? ctx->sideStream : ctx->stream));
         ctx->accWriterPending[s] = true;
         ctx->accWriterFull[s] = full;
+        if (full) {
+            HIP_TRY(ctx, hipEventRecord(ctx->evAccFull[s], s ? ctx->sideStream : ctx->stream));
+            ctx->accFullPending[s] = true;
+        }
         return RT_OK;
     };
     for (int p = 0; p < parts; p++) {

@@ -599,6 +599,36 @@ def test_alternating_fused_launches_add_frames_in_frame_order(pkg, api, orc, alt
         assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32)), (cfg, alternate)
 
 
+@pytest.mark.parametrize("alternate", ["0", "1"])
+def test_a_single_frame_behind_a_fused_launch_waits_for_its_accumulate_kernel(pkg, api, orc, alternate, monkeypatch):
+    """rt_render_frames(17) = one fused launch of 16 frames + one two-part frame, back to back.  The half of that frame that runs on
+    the OTHER stream must come after the fused launch's accumulate kernel (found by tools/soak.py in round 4: the half kernel launched
+    behind the accumulate kernel on the same stream re-recorded the stream's writer event as 'half', and the other half no longer
+    waited — a frame lost in the pixels both were adding to, or added out of order).  Several shapes, several times: the race needs
+    the two kernels to meet."""
+    monkeypatch.setenv("RT_ALTERNATE", alternate)
+    w, h = 200, 120
+    sc = pkg.scenes.get(2)
+    c = orc.create_tracer(16)
+    mo = sc.make_manager(c, orc, w, h)
+    mo.OnEnable(renderSeed=5)
+    shapes = (17, 33, 1, 16, 1, 18, 17)
+    want = []
+    for n in shapes:
+        mo.RenderFrames(n)
+        want.append(c.read_accumulated().copy())
+    c.close()
+    for rep in range(6):
+        tr = api.create_tracer(0)
+        mgr = pkg.scenes.get(2).make_manager(tr, api, w, h)
+        mgr.OnEnable(renderSeed=5)
+        for n, ref in zip(shapes, want):
+            mgr.RenderFrames(n)
+            got = tr.read_accumulated()
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (alternate, rep, n, int(np.any(got.view(np.uint32) != ref.view(np.uint32), axis=-1).sum()))
+        tr.close()
+
+
 @pytest.mark.parametrize("coalesce", ["0", "1"])
 def test_held_back_frames_see_the_state_they_were_requested_with(pkg, api, orc, coalesce, monkeypatch):
     """rt_render_frame holds frames requested while the GPU is busy back and launches them fused.  Every call that
