@@ -175,3 +175,50 @@ def test_validate_scene_refuses_what_upload_scene_refuses(pkg, api, monkeypatch,
                 assert got["n_pairs"] > 0
             except a.RtError as e:      # only a triangle-range refusal is acceptable here (the grafted leaves use the other mesh's triOffset)
                 assert e.status == a.RT_ERR_SCENE and "out of bounds" in str(e)
+
+
+def test_validate_scene_fuzz_parallel_and_sequential_agree(pkg, api, monkeypatch):
+    """Corrupted scenes (random child indices, triangle counts, bit flips in the node array, model offsets, links between subtrees,
+    NaN / inf bounds): never a crash or a hang, and the worker-thread preparation accepts and refuses exactly what the sequential walk
+    does — with the same status, tree height and filter count."""
+    import numpy as np
+    a = pkg.abi
+    data, sph = _scene_arrays(pkg, api, 4)
+    rng = np.random.default_rng(1)
+
+    def outcome(models, tris, nodes, seq):
+        if seq:
+            monkeypatch.setenv("RT_SEQUENTIAL_PREPARE", "1")
+        else:
+            monkeypatch.delenv("RT_SEQUENTIAL_PREPARE", raising=False)
+        try:
+            i = api.validate_scene_arrays(models, tris, nodes, sph)
+            return ("ok", i["max_height"], i["flat"], i["n_filtered"])
+        except a.RtError as e:
+            return ("err", e.status)
+
+    seen = {"ok": 0, "err": 0}
+    for it in range(150):
+        nodes, models, tris = data["nodes"].copy(), data["meshInfo"].copy(), data["triangles"]
+        kind = it % 6
+        for _ in range(int(rng.integers(1, 6))):
+            i = int(rng.integers(0, len(nodes)))
+            if kind == 0:
+                nodes[i]["startIndex"] = int(rng.integers(-5, len(nodes) + 5))
+            elif kind == 1:
+                nodes[i]["triangleCount"] = int(rng.integers(-3, 200))
+            elif kind == 2:
+                raw = nodes.view(np.uint8)
+                raw[int(rng.integers(0, raw.size))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+            elif kind == 3:
+                m = int(rng.integers(0, len(models)))
+                models[m]["nodeOffset"] = int(rng.integers(-2, len(nodes) + 2))
+                models[m]["triOffset"] = int(rng.integers(-2, len(tris) + 2))
+            elif kind == 4:
+                nodes[i]["startIndex"] = nodes[int(rng.integers(0, len(nodes)))]["startIndex"]
+            else:
+                nodes[i]["boundsMin"][int(rng.integers(0, 3))] = [np.nan, np.inf, -np.inf][int(rng.integers(0, 3))]
+        o1, o2 = outcome(models, tris, nodes, False), outcome(models, tris, nodes, True)
+        assert o1 == o2, (it, kind, o1, o2)
+        seen[o1[0]] += 1
+    assert seen["ok"] > 10 and seen["err"] > 10, seen

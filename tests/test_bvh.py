@@ -274,3 +274,27 @@ def test_gpu_batch_builder_writes_the_concatenated_arrays(pkg, api):
     for o in out:
         assert o[0].tobytes() == ref[0].tobytes() and o[1].tobytes() == ref[1].tobytes()
     api.build_bvh_gpu_release()
+
+
+def _run_bvh_fuzz(*args):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bvh_fuzz.py"), *[str(x) for x in args]], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "BVH FUZZ OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_builder_fuzz_host_threads_and_reference_text(pkg):
+    """tools/bvh_fuzz.py without a device: random soups, clusters, sheets, duplicates, huge / tiny / non-finite coordinates — the host builder
+    on 1 and 5 threads (and the reference's own BVH.cs compiled as C++, where oracle/_ref holds it) against rt_build_bvh, byte for byte,
+    refusals alike."""
+    out = _run_bvh_fuzz(80, 2500, 11)
+    assert "80 meshes" in out
+
+
+@pytest.mark.gpu
+def test_builder_fuzz_gpu_single_and_forest(pkg):
+    """The same fuzz with rt_build_bvh_gpu and random batches through rt_build_bvh_gpu_batch (one forest per batch)."""
+    out = _run_bvh_fuzz(120, 5000, 12)
+    assert "gpu True" in out
