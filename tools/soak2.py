@@ -1,11 +1,17 @@
 """Randomised API soak, wider than tools/soak.py: random call sequences (rt_render_frame bursts, rt_render_frames(n) with every residue
-mod 16, reads of either buffer, counters, resets, model / sphere / parameter updates, accumulate off and on, resizes, flushes, synchronises)
+mod 16, reads of either buffer, counters, resets, model / sphere / parameter updates, accumulate off and on, resizes, flushes, synchronises, stats on / off, checkpoint
+write-back, display reads, scene re-uploads, switches to a caller-provided stream and back)
 on one context, on a partitioned context and through rt_create_multi — each run under the default schedule and under the plainest one (one
 stream, one launch per frame, identity order, nothing held back); every checkpoint and the final buffers must agree bit for bit.
 usage: python tools/soak2.py [rounds=120] [seeds=3] [configs=2,3,6]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+try:  # torch first: it carries its own HIP runtime, and the one loaded first owns the device for the process
+    import torch
+    caller_stream = torch.cuda.Stream() if torch.cuda.is_available() else None   # a caller-provided stream for rt_set_stream
+except Exception:
+    caller_stream = None
 import __graft_entry__ as g
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 120
@@ -33,6 +39,7 @@ def run(plain, cfg, seed, mode):
     mgr = sc.make_manager(tr, api, w, h)
     mgr.OnEnable(renderSeed=seed)
     rng = np.random.default_rng(seed * 1000 + cfg)
+    stats_on, on_caller = [False], [False]
     sig, log = [], []
     frames = 0
     for r in range(rounds):
@@ -50,7 +57,7 @@ def run(plain, cfg, seed, mode):
             if mgr.accumulate:
                 mgr.numAccumulatedFrames += n
         frames += n
-        ev = int(rng.integers(0, 12))
+        ev = int(rng.integers(0, 17))
         log.append((r, how, n, ev))
         if ev == 0:
             sig.append(("acc", r, int(np.ascontiguousarray(tr.read_accumulated()).view(np.uint32).sum(dtype=np.uint64))))
@@ -84,7 +91,25 @@ def run(plain, cfg, seed, mode):
             mgr.tracer.update_spheres(mgr._pack_spheres())
         elif ev == 10:
             mgr.numRaysPerPixel = int(rng.integers(1, 4))
+        elif ev == 11 and mode != "multi":
+            stats_on[0] = not stats_on[0]
+            tr.enable_stats(stats_on[0])              # the other kernel instantiation (exact counters, audits) from here on
+        elif ev == 12 and mode != "multi":
+            tr.write_accumulated(tr.read_accumulated())   # checkpoint / resume: the sum goes out and comes back
+        elif ev == 13 and mode != "multi":
+            img = tr.display_srgb8(max(1, mgr.numAccumulatedFrames - 1)) if r % 2 else tr.display(max(1, mgr.numAccumulatedFrames - 1))
+            sig.append(("display", r, int(np.ascontiguousarray(img).view(np.uint8).sum(dtype=np.uint64))))
+        elif ev == 14:
+            mgr.hasBVH = False                        # the scene again: CreateAllMeshData + rt_upload_scene with frames possibly in flight
+            mgr.InitFrame()
+        elif ev == 15 and mode == "single" and caller_stream is not None:
+            on_caller[0] = not on_caller[0]
+            tr.set_stream(caller_stream.cuda_stream if on_caller[0] else None)   # the caller's stream order is then the contract
+        elif ev == 16 and hasattr(tr, "flush"):
+            tr.flush()
     acc = np.ascontiguousarray(tr.read_accumulated()).copy(); frm = np.ascontiguousarray(tr.read_frame()).copy()
+    if on_caller[0]:
+        tr.set_stream(None)
     tr.close()
     return acc, frm, sig, frames, log
 
