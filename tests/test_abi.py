@@ -222,3 +222,42 @@ def test_validate_scene_fuzz_parallel_and_sequential_agree(pkg, api, monkeypatch
         assert o1 == o2, (it, kind, o1, o2)
         seen[o1[0]] += 1
     assert seen["ok"] > 10 and seen["err"] > 10, seen
+
+
+def test_header_is_plain_c_and_links_from_a_c_program(pkg, api, tmp_path):
+    """include/rt_abi.h is the boundary a C# / C / Rust host binds: it must compile as C99 (pedantic), and a C program must link
+    against libraytrace_hip.so and call it without a GPU (version string, host-side scene validation, the host BVH builder)."""
+    import subprocess
+    src = tmp_path / "host.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "rt_abi.h"
+int main(void)
+{
+    RtSceneInfo info;
+    float verts[9] = {0, 0, 0, 1, 0, 0, 0, 1, 0}, normals[9] = {0, 0, 1, 0, 0, 1, 0, 0, 1};
+    int32_t idx[3] = {0, 1, 2};
+    RtBVHNode nodes[2];
+    RtTriangle tri[1];
+    RtBvhStats stats;
+    RtModel model;
+    int n_nodes = 0;
+    if (rt_build_bvh(verts, normals, 3, idx, 3, RT_BVH_QUALITY_HIGH, nodes, &n_nodes, tri, &stats) != RT_OK || n_nodes != 1) return 2;
+    memset(&model, 0, sizeof model);
+    model.worldToLocal[0] = model.worldToLocal[5] = model.worldToLocal[10] = model.worldToLocal[15] = 1.0f;
+    model.localToWorld[0] = model.localToWorld[5] = model.localToWorld[10] = model.localToWorld[15] = 1.0f;
+    if (rt_validate_scene(&model, 1, tri, 1, nodes, n_nodes, NULL, 0, &info) != RT_OK || !info.flat) return 3;
+    nodes[0].triangleCount = 5; /* a leaf that runs past the triangle buffer */
+    if (rt_validate_scene(&model, 1, tri, 1, nodes, n_nodes, NULL, 0, &info) != RT_ERR_SCENE) return 4;
+    printf("%s | %s\n", rt_version(), rt_last_error(NULL));
+    return 0;
+}
+''')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lraytrace_hip", "-Wl,-rpath," + libdir])
+    out = subprocess.check_output([str(exe)], text=True)
+    assert "raytrace_hip gfx950" in out and "out of bounds" in out
