@@ -750,6 +750,43 @@ def test_far_camera_disables_filter_safely(pkg, api, orc):
 
 
 # ------------------------------------------------------------------ error behaviour of the ABI
+def test_contexts_driven_from_several_host_threads(pkg, api, orc):
+    """One context is externally synchronised; DIFFERENT contexts may be driven from different host threads at the same time (a host
+    that renders several views): four threads, four contexts on the same GPU, each with its own scene / size / seed, interleaved
+    frames, reads and counters — every thread gets the oracle's bits."""
+    import threading
+    jobs = [(2, 120, 72, 3), (3, 96, 56, 7), (6, 88, 48, 11), (3, 61, 35, 13)]
+    want = {}
+    for k, (cfg, w, h, seed) in enumerate(jobs):
+        c = orc.create_tracer(8)
+        b, _ = render(pkg, orc, c, cfg, w, h, 6, seed)
+        want[k] = (b.copy(), c.counters()["segments"])
+        c.close()
+    got, errors = {}, []
+
+    def work(k, cfg, w, h, seed):
+        try:
+            tr = api.create_tracer(0)
+            mgr = pkg.scenes.get(cfg).make_manager(tr, api, w, h)
+            mgr.OnEnable(renderSeed=seed)
+            for i in range(6):
+                mgr.RenderFrame()
+                if i % 2:
+                    tr.read_frame()
+            got[k] = (tr.read_accumulated().copy(), tr.counters()["segments"])
+            tr.close()
+        except Exception as e:   # pragma: no cover
+            errors.append((k, repr(e)))
+
+    for rep in range(3):
+        th = [threading.Thread(target=work, args=(k, *j)) for k, j in enumerate(jobs)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errors, errors
+        for k in want:
+            assert bits_equal(got[k][0], want[k][0]) and got[k][1] == want[k][1], (rep, k)
+
+
 def test_abi_errors(pkg, api):
     a = pkg.abi
     tr = api.create_tracer(0)
