@@ -73,3 +73,47 @@ def test_csharp_imports_exist_in_header():
     assert len(imports) >= 20
     for name in imports:
         assert re.search(r"\b%s\s*\(" % name, header), name
+
+
+def _split_params(s):
+    s = s.strip()
+    if not s or s == "void":
+        return []
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([<":
+            depth += 1
+        elif ch in ")]>":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    out.append(cur.strip())
+    return out
+
+
+def test_csharp_imports_have_the_headers_parameter_counts_and_the_host_uses_only_imports():
+    """The P/Invoke declarations cannot be compiled here: every DllImport must at least take as many parameters as the C function it
+    binds (a missing `int n_spheres` would corrupt the stack at run time), return int / void / IntPtr / double as the header does, and
+    Program.cs may only call functions RayTraceNative declares."""
+    cs = open(os.path.join(ROOT, "host", "dotnet", "RayTraceNative.cs")).read()
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rt_abi.h")).read(), flags=re.S)
+    c_funcs = {m.group(2): (m.group(1).strip(), _split_params(m.group(3)))
+               for m in re.finditer(r"^\s*((?:const\s+)?[A-Za-z_][\w\s\*]*?)\b(rt_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.M | re.S)}
+    imports = {m.group(2): (m.group(1), _split_params(m.group(3)))
+               for m in re.finditer(r"public static extern (\w+) (rt_\w+)\(([^;]*?)\);", cs, flags=re.S)}
+    assert len(imports) >= 30
+    ret = {"int": "int", "void": "void", "double": "double"}
+    for name, (rtype, params) in imports.items():
+        assert name in c_funcs, name
+        ctype, cparams = c_funcs[name]
+        assert len(params) == len(cparams), (name, params, cparams)
+        if "*" in ctype:
+            assert rtype == "IntPtr", (name, ctype, rtype)
+        else:
+            assert ret.get(ctype.replace("const ", "").strip()) == rtype, (name, ctype, rtype)
+    prog = open(os.path.join(ROOT, "host", "dotnet", "Program.cs")).read()
+    for name in set(re.findall(r"RayTraceNative\.(rt_\w+)\(", prog)):
+        assert name in imports, name
