@@ -170,6 +170,26 @@ namespace RayTraceHost
         [DllImport(Lib)] public static extern int rt_multi_peer_access(IntPtr multi, out int pairs, out int enabled);
         [DllImport(Lib)] public static extern int rt_gather_accumulated_to_device(IntPtr multi, int root, IntPtr d_rgba, UIntPtr bytes);
         [DllImport(Lib)] public static extern int rt_gather_frame_to_device(IntPtr multi, int root, IntPtr d_rgba, UIntPtr bytes);
+        // the rest of include/rt_abi.h (display blit, checkpoint, caller stream / caller-owned targets, statistics, the other builders)
+        [DllImport(Lib)] public static extern IntPtr rt_version();
+        [DllImport(Lib)] public static extern int rt_set_stream(IntPtr ctx, IntPtr hip_stream);
+        [DllImport(Lib)] public static extern int rt_local_to_global_row(IntPtr ctx, int local_row);
+        [DllImport(Lib)] public static extern int rt_bind_render_targets(IntPtr ctx, IntPtr d_frame_render, IntPtr d_accumulated);
+        [DllImport(Lib)] public static extern int rt_get_render_targets(IntPtr ctx, out IntPtr d_frame_render, out IntPtr d_accumulated);
+        [DllImport(Lib)] public static extern int rt_flush(IntPtr ctx);
+        [DllImport(Lib)] public static extern int rt_display(IntPtr ctx, int frame, int use_accumulated, [Out] float[] rgba, UIntPtr bytes);
+        [DllImport(Lib)] public static extern int rt_display_srgb8(IntPtr ctx, int frame, int use_accumulated, int flip_y, [Out] byte[] rgba8, UIntPtr bytes);
+        [DllImport(Lib)] public static extern int rt_write_accumulated(IntPtr ctx, [In] float[] rgba, UIntPtr bytes);
+        [DllImport(Lib)] public static extern int rt_enable_stats(IntPtr ctx, int enabled);
+        [DllImport(Lib)] public static extern int rt_multi_count(IntPtr multi);
+        [DllImport(Lib)] public static extern int rt_multi_update_spheres(IntPtr multi, [In] RtSphere[] spheres, int n_spheres);
+        [DllImport(Lib)] public static extern int rt_gather_frame(IntPtr multi, [Out] float[] rgba, UIntPtr bytes);
+        [DllImport(Lib)] public static extern int rt_build_bvh_mt([In] float[] verts, [In] float[] normals, int n_verts,
+            [In] int[] indices, int n_indices, int quality, int n_threads, [Out] RtBVHNode[] out_nodes, out int out_n_nodes,
+            [Out] RtTriangle[] out_tris, IntPtr out_stats);
+        [DllImport(Lib)] public static extern int rt_build_bvh_gpu(int device_id, [In] float[] verts, [In] float[] normals, int n_verts,
+            [In] int[] indices, int n_indices, int quality, [Out] RtBVHNode[] out_nodes, out int out_n_nodes,
+            [Out] RtTriangle[] out_tris, IntPtr out_stats);
         [DllImport(Lib)] public static extern void rt_build_bvh_gpu_release();
         [DllImport(Lib)] public static extern int rt_build_bvh_gpu_batch(int device_id, int n_meshes, IntPtr[] verts, IntPtr[] normals, int[] n_verts, IntPtr[] indices, int[] n_indices, int quality, IntPtr out_nodes, int[] out_n_nodes, int[] out_node_offset, IntPtr out_tris, int[] out_tri_offset, IntPtr out_stats);
 
