@@ -26,7 +26,7 @@
 #ifndef RT_KERNELS_Q_H
 #define RT_KERNELS_Q_H
 
-#include "rt_kernels.h"
+#include "../rt_kernels.h"
 
 #ifndef RT_Q_R
 #define RT_Q_R 3 /* pixel chains per traversal lane */

@@ -25,11 +25,11 @@
 #include <thread>
 #include <unordered_map>
 
-#ifdef RT_WG_EXPERIMENT /* make wg: the queued stages with the parked chains in a workgroup-wide LDS pool (rt_kernels_wg.h) */
+#ifdef RT_WG_EXPERIMENT /* make wg: the queued stages with the parked chains in a workgroup-wide LDS pool (experiments/rt_kernels_wg.h) */
 #define RT_QUEUED_EXPERIMENT
-#include "rt_kernels_wg.h"
+#include "experiments/rt_kernels_wg.h"
 #elif defined(RT_QUEUED_EXPERIMENT) /* make queued: the queued-stages form of the trace kernel, measured 3x slower */
-#include "rt_kernels_q.h"
+#include "experiments/rt_kernels_q.h"
 #else
 #include "rt_kernels.h"
 #endif

@@ -159,10 +159,10 @@ struct KArgs {
     int32_t launchTiles, orderOffset, orderStride;
     int32_t launchItems;         /* queue positions of this launch: launchTiles, or launchTiles * frameGroups (tile, frame group) items */
     float4* pxCold;              /* per-wave pixel records of this launch: [grid][64 lanes][2] float4 (rt_kernels.h, PX_COLD) */
-    uint32_t* qRecords;          /* queued-stages kernel (rt_kernels_q.h): per-wave chain records + parked traversal state, [grid][RT_Q_WAVE_DWORDS] */
+    uint32_t* qRecords;          /* queued-stages kernel (experiments/rt_kernels_q.h): per-wave chain records + parked traversal state, [grid][RT_Q_WAVE_DWORDS] */
     int32_t qFlushMin;           /* traversal lanes hand their results over when this many have finished */
     int32_t qRefillMin;          /* free traversal lanes are refilled from rayQ when this many are free */
-    int32_t wgTravWaves;         /* workgroup kernel (rt_kernels_wg.h): traversal waves per eight-wave workgroup */
+    int32_t wgTravWaves;         /* workgroup kernel (experiments/rt_kernels_wg.h): traversal waves per eight-wave workgroup */
     int32_t wgPool;              /* ... and its pool of parked chains (slots) */
     int32_t qStarveMin;          /* fewer rays than this in and before the traversal lanes: partial batches run */
     int32_t frameGroup;          /* consecutive frames per item (>= 1) */

@@ -543,7 +543,7 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
     const DPair* __restrict__ pairs = a.pairs;
     const DTri* __restrict__ tris = a.tris;
     /* the loop runs while more than keepAbove lanes are still traversing: entered * a.suspendNum / RT_SUSPEND_DEN (3/8 unless the
-     * launch tuner found 4/8 faster for this scene) — or what the caller says (the queued-stages kernel, rt_kernels_q.h) */
+     * launch tuner found 4/8 faster for this scene) — or what the caller says (the queued-stages kernel, experiments/rt_kernels_q.h) */
     const int enteredNum = keepAboveArg >= 0 ? keepAboveArg * RT_SUSPEND_DEN : SUSPEND ? __popcll(__ballot(1)) * a.suspendNum : 0;
     phase_mark<STATS>(st, PH_TRAVERSE_CALL);
     /* One kind of work per iteration, chosen for the whole wave: the kind most lanes are
