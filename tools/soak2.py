@@ -39,7 +39,7 @@ def run(plain, cfg, seed, mode):
     mgr = sc.make_manager(tr, api, w, h)
     mgr.OnEnable(renderSeed=seed)
     rng = np.random.default_rng(seed * 1000 + cfg)
-    stats_on, on_caller = [False], [False]
+    stats_on, on_caller, bound = [False], [False], [None]
     sig, log = [], []
     frames = 0
     for r in range(rounds):
@@ -57,7 +57,7 @@ def run(plain, cfg, seed, mode):
             if mgr.accumulate:
                 mgr.numAccumulatedFrames += n
         frames += n
-        ev = int(rng.integers(0, 17))
+        ev = int(rng.integers(0, 18))
         log.append((r, how, n, ev))
         if ev == 0:
             sig.append(("acc", r, int(np.ascontiguousarray(tr.read_accumulated()).view(np.uint32).sum(dtype=np.uint64))))
@@ -78,7 +78,7 @@ def run(plain, cfg, seed, mode):
         elif ev == 6:
             mgr.accumulate = not mgr.accumulate       # RCM:94: the frame counter stands still while accumulation is off
             mgr.SetShaderParams()
-        elif ev == 7 and mode == "single":
+        elif ev == 7 and mode == "single" and bound[0] is None:
             w, h = sizes[1] if (w, h) == sizes[0] else sizes[0]
             mgr.screenSize = (w, h)                   # a resize: new targets, accumulation restarts (InitTexturesAndBuffers, RCM:126-141)
             mgr._sized = False
@@ -107,9 +107,22 @@ def run(plain, cfg, seed, mode):
             tr.set_stream(caller_stream.cuda_stream if on_caller[0] else None)   # the caller's stream order is then the contract
         elif ev == 16 and hasattr(tr, "flush"):
             tr.flush()
+        elif ev == 17 and mode != "multi" and caller_stream is not None:
+            if bound[0] is None:                      # caller-owned render targets (e.g. tensors for an RCCL gather), frames possibly in flight
+                rows = tr.local_rows()
+                bound[0] = (torch.empty((rows, w, 4), dtype=torch.float32, device="cuda"), torch.empty((rows, w, 4), dtype=torch.float32, device="cuda"))
+                tr.bind_render_targets(bound[0][0].data_ptr(), bound[0][1].data_ptr())
+            else:
+                tr.bind_render_targets(None, None)    # back to the library's own buffers
+                tr.synchronize()
+                bound[0] = None
+            mgr.ResetAccumulatedRender()              # the new targets hold nothing yet
     acc = np.ascontiguousarray(tr.read_accumulated()).copy(); frm = np.ascontiguousarray(tr.read_frame()).copy()
     if on_caller[0]:
         tr.set_stream(None)
+    if bound[0] is not None:
+        tr.bind_render_targets(None, None)
+        tr.synchronize()
     tr.close()
     return acc, frm, sig, frames, log
 
