@@ -435,11 +435,19 @@ def main():
     dev_index = 0 if os.environ.get("RT_BENCH_ONE_DEVICE") else local_rank
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(dev_index)
-    pinned_cpus = pin_to_gpu_numa_node(torch, dev_index) if world > 1 and not os.environ.get("RT_BENCH_ONE_DEVICE") else None
+    pinned_cpus = (pin_to_gpu_numa_node(torch, dev_index)
+                   if (world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1") and not os.environ.get("RT_BENCH_ONE_DEVICE") else None)
     device = torch.device("cuda", dev_index)
     comm_device = device if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1: a ONE-rank job takes the distributed path all the same (process group on the chosen backend, partition
+    # 1/1, bound render targets, the gather collective, all_reduce / all_gather_object) — the driver's SCALE run's RCCL code executes
+    # on a 1-GPU box (tests/test_zz_dist_gpu.py)
+    dist_on = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -455,8 +463,8 @@ def main():
         f = world ** 0.5
         W, H = int(round(W * f / 8)) * 8, int(round(H * f / 8)) * 8
     tiled = None
-    if world > 1:
-        tiled = pkg.dist.TiledTracer(tracer, rank, world, device)
+    if dist_on:
+        tiled = pkg.dist.TiledTracer(tracer, rank, world, device, always_collective=True)
     mgr = scene.make_manager(tracer, api, W, H)
     mgr.bvhOnGpu = True         # CreateAllMeshData through rt_build_bvh_gpu_batch: the scene's meshes as one forest, byte-identical trees
     mgr.bvhDevice = dev_index   # on this rank's GPU
@@ -475,7 +483,7 @@ def main():
     accumulated = [0]         # frames added into the accumulation buffer since its last reset (every pass below adds K)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         tracer.synchronize()
         torch.cuda.synchronize()
@@ -609,7 +617,7 @@ def main():
 
     # ---- who took part: one record per rank, collected with the job's own backend (RCCL when N GPUs are there)
     devices_seen = None
-    if world > 1:
+    if dist_on:
         props = torch.cuda.get_device_properties(dev_index)
         me = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "name": props.name,
               "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
@@ -618,7 +626,7 @@ def main():
         devices_seen = [None] * world
         dist.all_gather_object(devices_seen, me)
 
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed, float(timed["gpuMs"]), init_elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms_max, init_elapsed = t[0].item(), t[1].item(), t[2].item()
@@ -631,7 +639,7 @@ def main():
         total_bytes = float(pkg.abi.algorithmic_bytes(stats, n_models, n_spheres))
 
     diagnostics_all = diagnostics
-    if world > 1:
+    if dist_on:
         lists = [None] * world
         dist.all_gather_object(lists, diagnostics)
         diagnostics_all = [d_ for l_ in lists for d_ in l_]
@@ -641,9 +649,9 @@ def main():
         spp, mb = scene.settings["numRaysPerPixel"], scene.settings["maxBounceCount"]
         # ---- VALU roofline of the dominant (only) kernel
         pmc = None
-        if world == 1 and not args.no_pmc:
+        if not dist_on and not args.no_pmc:
             pmc = collect_pmc(args.config, 3, 1, with_traffic=True, fpl=fpl)
-        if pmc is None and world == 1:
+        if pmc is None and not dist_on:
             pmc = replayed_pmc(args.config, fpl)
         roof = None
         if pmc is not None:
@@ -661,7 +669,7 @@ def main():
             roof["secondary_hbm_algorithmic"]["void"] = roof["secondary_hbm_algorithmic"]["frac_of_peak"] > 1.0
             roof["fetch_size_factor"] = {"factor": 2.0, "calibration": "profiles/r04_fetch_size_calibration.txt (streaming and divergent 64-B / 48-B per-lane "
                                                                        "record fetches: FETCH_SIZE adds 64 B per 128-B line fill)"}
-        parity = parity_check(pkg, api, dev_index, args.config, W, H, (3, H // 16, H // 8 - 2)) if world == 1 else None
+        parity = parity_check(pkg, api, dev_index, args.config, W, H, (3, H // 16, H // 8 - 2)) if not dist_on else None
         out = {
             "metric": f"Mrays/s at {W}x{H}, {spp} spp, {mb} bounces; per-channel L2 vs reference",
             "value": total_segments / elapsed / 1e6,
@@ -689,7 +697,7 @@ def main():
             "ms_per_step_with_initframe": init_elapsed / args.steps * 1e3,
             "gather_ms": gather_ms, "gather_error": gather_error, "gathered_image_complete": gather_alpha_ok,
             "gathered_image": gathered,
-            "ranks_seen": (dist.get_world_size() if world > 1 else 1), "devices_seen": devices_seen,
+            "ranks_seen": (dist.get_world_size() if dist_on else 1), "devices_seen": devices_seen,
             "distinct_devices": (len({(d_["uuid"], d_["pci_bus_id"]) for d_ in devices_seen}) if devices_seen else 1),
             "diagnostics": diagnostics_all,
             "launches": ("K x rt_render_frame, back to back: the library starts an idle GPU at once (frame 1: 2 kernels on 2 streams, disjoint "
@@ -707,7 +715,7 @@ def main():
             "roofline": roof,
         }
         # ---- the same roofline for BVH workloads (north_star's roofline clause is about BVH traversal, RC:234-287)
-        if world == 1 and args.config == 2 and not args.no_secondary:
+        if not dist_on and args.config == 2 and not args.no_secondary:
             sec = {}
             for cfg in (3, 4):
                 sc2 = pkg.scenes.get(cfg)
@@ -727,7 +735,7 @@ def main():
                         r2["gpu_over_cpu"] = r2["mrays_per_s_fused_launches"] / cb["value"]
                 sec[f"config{cfg}"] = r2
             out["secondary"] = sec
-        if world == 1 and not args.no_cpu_baseline:
+        if not dist_on and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, args.config, W, H)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             # informational: the same port on the host's cores (row bands of the image per thread)
@@ -742,7 +750,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     tracer.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     if diagnostics_all:

@@ -386,6 +386,27 @@ int rt_debug_intersect(RtContext* ctx, const float* origins, const float* dirs, 
  * op: 0 log, 1 exp, 2 sin, 3 cos, 4 sqrt, 5 pow(x,y), 6 x/y, 7 smoothstep(0,y,x). */
 int rt_debug_math_eval(RtContext* ctx, int op, const float* x, const float* y, float* out, int n);
 
+/* The device-memory layout rt_upload_scene would produce for these buffers, on the host (no device needed) — for the
+ * host-side layout tests and tools/layout_sim: every record is named by the 16-byte unit it starts at (inner code = unit of
+ * a 64-byte pair record in pair_space; leaf code = bit 31 | count << 24 | first unit of the run of 48-byte triangle
+ * records relative to tri_base[model], count 0 = index into big_leaves {unit, count}; norm_space holds 12 bytes per unit of
+ * the triangle space).  `layout` = an RT_LAYOUT string or NULL (environment / default).  arena = 1: the triangles live in
+ * pair_space (tri_space is NULL).  Free with rt_debug_layout_free. */
+typedef struct RtLayoutDump {
+    unsigned char* pair_space; size_t pair_bytes;
+    unsigned char* tri_space;  size_t tri_bytes;
+    unsigned char* norm_space; size_t norm_bytes;
+    uint32_t* big_leaves;      size_t n_big_leaves; /* pairs of (unit, count) */
+    uint32_t* root_codes;      /* per model */
+    int32_t* tri_base;         /* per model, units */
+    int32_t n_models;
+    int32_t arena;
+    char used[64];             /* the layout that was applied (an irregular scene gets "dense") */
+} RtLayoutDump;
+int rt_debug_layout(const RtModel* models, int n_models, const RtTriangle* triangles, int n_triangles,
+                    const RtBVHNode* nodes, int n_nodes, const char* layout, RtLayoutDump* out);
+void rt_debug_layout_free(RtLayoutDump* dump);
+
 /* Wave-level divergence profile of the frames rendered with stats enabled since the
  * last rt_reset_counters: out[2p] = times a wave executed phase p, out[2p+1] = lanes
  * active in it (p: 0 loop, 1 camera ray, 2 spheres, 3 traverse call, 4 model setup,

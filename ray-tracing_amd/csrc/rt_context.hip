@@ -37,6 +37,7 @@
 #ifndef RT_MAX_FUSED_FRAMES
 #define RT_MAX_FUSED_FRAMES 16
 #endif
+#include "rt_layout.h"
 #define RT_VERSION_STRING "raytrace_hip gfx950 abi=1"
 
 static thread_local char g_err[512] = "";
@@ -70,9 +71,13 @@ struct RtContext {
     float sphereBound = 0;     /* max over spheres of |c|^2 + r*r, rounded up */
     DMaterial* dMaterials = nullptr;
     DModel* dModels = nullptr;
-    DPair* dPairs = nullptr;
-    DTri* dTris = nullptr;
-    DTriN* dNorms = nullptr;
+    /* the traversal's records, addressed in 16-byte units (rt_layout.h decides where they lie) */
+    unsigned char* dPairs = nullptr; /* pair space */
+    unsigned char* dTris = nullptr;  /* triangle space; null when the layout keeps the triangles in the pair space (arena) */
+    unsigned char* dNorms = nullptr; /* 12 bytes per unit of the triangle space */
+    bool arenaLayout = false;
+    RtLayout layout;                 /* RT_LAYOUT at rt_create */
+    std::string layoutUsed = "dense";
     uint32_t* dBigLeaves = nullptr;
     DFilter* dFilters = nullptr;
     DChunk* dChunks = nullptr;  /* two-level model hierarchy, scenes with more than 64 models */
@@ -87,6 +92,7 @@ struct RtContext {
     /* scene (host mirrors needed by rt_update_models) */
     std::vector<RtModel> hModels;
     std::vector<uint32_t> hRootCodes;
+    std::vector<int32_t> hTriBase; /* per model: first unit of its triangles in the triangle space */
 
     /* uniforms */
     RtParams params;
@@ -112,6 +118,12 @@ struct RtContext {
     long long framesSinceResize = 0;
     long long nextSortAt = 1;
     bool lptEnabled = true;
+    /* EXPERIMENT RT_XCD_AFFINITY=1|2 (fused launches): per-XCD ranges of the tile queue (KArgs::xcdQueues); 2 = LPT off and a static
+     * order in which the eight ranges are eight compact blocks of the image (4 x 2) */
+    int xcdAffinity = 0;
+    unsigned long long* dXcdQueues = nullptr; /* 2 launch slots x 8 counters */
+    uint32_t* dBlockOrder = nullptr;
+    int blockOrderTiles = 0;
     int numCUs = 256;
     int occPerCU[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     size_t occBytes[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -347,6 +359,8 @@ int rt_create(int device_id, RtContext** out)
     if (getenv("RT_VERBOSE")) ctx->verbose = true;
     if (const char* f = getenv("RT_FUSE_FRAMES")) ctx->fuseFrames = atoi(f) != 0;
     if (const char* l = getenv("RT_LPT")) ctx->lptEnabled = atoi(l) != 0;
+    if (const char* l = getenv("RT_XCD_AFFINITY")) ctx->xcdAffinity = atoi(l);
+    if (ctx->xcdAffinity == 2) ctx->lptEnabled = false;
     if (const char* t = getenv("RT_TWO_STREAMS")) ctx->twoStreams = atoi(t) != 0;
     if (const char* c = getenv("RT_COALESCE")) ctx->coalesce = atoi(c) != 0;
     if (const char* fg = getenv("RT_FRAME_GROUP")) ctx->frameGroupOverride = atoi(fg);
@@ -392,6 +406,8 @@ void rt_destroy(RtContext* ctx)
     hipFree(ctx->dTileOrder[0]);
     hipFree(ctx->dTileOrder[1]);
     hipFree(ctx->dTileKey);
+    hipFree(ctx->dXcdQueues);
+    hipFree(ctx->dBlockOrder);
     if (ctx->evSort) hipEventDestroy(ctx->evSort);
     for (int i = 0; i < 2; i++) if (ctx->evOrderRetire[i]) hipEventDestroy(ctx->evOrderRetire[i]);
     hipFree(ctx->dDisplay);
@@ -554,7 +570,7 @@ static void pack_material(const RtMaterial& m, DMaterial& d)
     d.ior = m.ior;
     d.flag = m.flag;
 }
-static void pack_model(const RtModel& m, uint32_t rootCode, DModel& d)
+static void pack_model(const RtModel& m, uint32_t rootCode, int32_t triBaseUnits, DModel& d)
 {
     memset(&d, 0, sizeof(d));
     for (int r = 0; r < 3; r++)
@@ -563,7 +579,7 @@ static void pack_model(const RtModel& m, uint32_t rootCode, DModel& d)
             d.l2w[r * 4 + c] = m.localToWorld[c * 4 + r];
         }
     d.rootCode = rootCode;
-    d.triBase = m.triOffset;
+    d.triBase = triBaseUnits;
     d.cullBackface = m.material.flag != RT_MATERIAL_GLASS; /* RC:355 */
 }
 
@@ -777,41 +793,6 @@ static void make_chunks(const std::vector<DFilter>& filters, std::vector<DChunk>
     }
 }
 
-/* Uninitialised storage for plain records that are about to be written in full (std::vector::resize would first zero
- * ~150 MB for a million triangles, on one thread: page faults, a third of rt_upload_scene's host time). */
-template <typename T>
-struct PodVec {
-    T* p = nullptr;
-    size_t n = 0;
-    PodVec() = default;
-    PodVec(const PodVec&) = delete;
-    PodVec& operator=(const PodVec&) = delete;
-    ~PodVec() { free(p); }
-    bool resize_uninit(size_t k)
-    {
-        free(p);
-        p = nullptr;
-        const size_t bytes = k * sizeof(T), huge = (size_t)2 << 20;
-        if (bytes >= 2 * huge) { /* fresh pages are the cost of a large scene's preparation: ask for 2 MB ones */
-            void* q = nullptr;
-            if (posix_memalign(&q, huge, (bytes + huge - 1) / huge * huge) == 0) {
-                madvise(q, (bytes + huge - 1) / huge * huge, MADV_HUGEPAGE);
-                p = static_cast<T*>(q);
-            }
-        } else if (k) {
-            p = static_cast<T*>(malloc(bytes));
-        }
-        n = p ? k : 0;
-        return k == 0 || p != nullptr;
-    }
-    void shrink(size_t k) { if (k < n) n = k; }
-    T* data() { return p; }
-    const T* data() const { return p; }
-    size_t size() const { return n; }
-    T& operator[](size_t i) { return p[i]; }
-    const T& operator[](size_t i) const { return p[i]; }
-};
-
 struct SceneBuilder {
     const RtBVHNode* nodes;
     int nNodes, nTris;
@@ -993,10 +974,9 @@ struct PreparedScene {
     float sphereBound = 0;
     std::vector<DMaterial> mats;
     std::vector<DModel> dmodels;
-    PodVec<DPair> pairs;
-    PodVec<DTri> dtris;
-    PodVec<DTriN> dnorms;
-    std::vector<uint32_t> bigLeaves;
+    PodVec<DPair> pairs; /* canonical form (SceneBuilder::convert); consumed by the layout */
+    LaidOutScene lay;    /* what is uploaded: pair / triangle / normal spaces, final codes */
+    size_t nPairs = 0;
     std::vector<DFilter> filters;
     std::vector<DChunk> chunks;
     int nFiltered = 0, extWords = 0;
@@ -1011,7 +991,7 @@ struct PreparedScene {
 
 /* errors are reported on `ctx` (may be any context of the caller) */
 static int prepare_scene(RtContext* ctx, const RtModel* models, int n_models, const RtTriangle* triangles, int n_triangles,
-                         const RtBVHNode* nodes, int n_nodes, const RtSphere* spheres, int n_spheres, PreparedScene& ps)
+                         const RtBVHNode* nodes, int n_nodes, const RtSphere* spheres, int n_spheres, PreparedScene& ps, const char* layoutOverride = nullptr)
 {
     if (n_models < 0 || n_triangles < 0 || n_nodes < 0 || n_spheres < 0 || (n_models && !models) || (n_triangles && !triangles) ||
         (n_nodes && !nodes) || (n_spheres && !spheres))
@@ -1149,46 +1129,43 @@ static int prepare_scene(RtContext* ctx, const RtModel* models, int n_models, co
     if (nPairs >= ((size_t)1 << 26) || (size_t)n_triangles * sizeof(DTri) >= ((size_t)1 << 32))
         return fail(ctx, RT_ERR_SCENE, "scene too large for 32-bit offsets: %zu node pairs (limit 2^26), %d triangles (limit 2^32 / 48)", nPairs, n_triangles);
 
-    /* ---- triangles: RC:190-192 are ray independent, pre-difference them (same fp32 ops) */
-    PodVec<DTri>& dtris = ps.dtris;
-    PodVec<DTriN>& dnorms = ps.dnorms;
-    if (!dtris.resize_uninit((size_t)n_triangles) || !dnorms.resize_uninit((size_t)n_triangles))
-        return fail(ctx, RT_ERR_OOM, "rt_upload_scene: out of host memory");
-    const int triBlock = 1 << 15;
-    parallel_jobs((n_triangles + triBlock - 1) / triBlock, [&](int blk) {
-        const int i1 = (blk + 1) * triBlock < n_triangles ? (blk + 1) * triBlock : n_triangles;
-        for (int i = blk * triBlock; i < i1; i++) {
-            const RtTriangle& t = triangles[i];
-            rt_f3 A = rt_v3(t.posA[0], t.posA[1], t.posA[2]);
-            rt_f3 B = rt_v3(t.posB[0], t.posB[1], t.posB[2]);
-            rt_f3 Cc = rt_v3(t.posC[0], t.posC[1], t.posC[2]);
-            rt_f3 ab = B - A, ac = Cc - A;
-            rt_f3 f = rt_cross(ab, ac);
-            DTri& d = dtris[i];
-            d.ax = A.x; d.ay = A.y; d.az = A.z;
-            d.abx = ab.x; d.aby = ab.y; d.abz = ab.z;
-            d.acx = ac.x; d.acy = ac.y; d.acz = ac.z;
-            d.fx = f.x; d.fy = f.y; d.fz = f.z;
-            memcpy(dnorms[i].n + 0, t.normA, 12);
-            memcpy(dnorms[i].n + 3, t.normB, 12);
-            memcpy(dnorms[i].n + 6, t.normC, 12);
+    /* ---- the layout: canonical pairs + the caller's triangles -> the pair / triangle / normal spaces the kernels address in
+     * 16-byte units (rt_layout.h); triangles are pre-differenced on the way (RC:190-192 are ray independent, same fp32 ops) */
+    {
+        RtLayout L;
+        const char* want = layoutOverride ? layoutOverride : getenv("RT_LAYOUT");
+        if (!parse_layout(want ? want : RT_LAYOUT_DEFAULT, &L)) return fail(ctx, RT_ERR_INVALID_ARG, "RT_LAYOUT=%s: unknown layout", want ? want : RT_LAYOUT_DEFAULT);
+        LayoutEngine eng;
+        eng.canon = ps.pairs.data();
+        eng.nCanon = nPairs;
+        eng.canonBig = &sb.bigLeaves;
+        eng.models = models;
+        eng.nModels = n_models;
+        eng.rootCodes = rootCodes.data();
+        eng.tris = triangles;
+        eng.nTris = n_triangles;
+        eng.parallel = [](int n, void* c, void (*f)(void*, int)) { parallel_jobs(n, [&](int k) { f(c, k); }); };
+        if (!eng.run(L, ps.pairs, ps.lay)) {
+            const bool oom = ps.lay.error == "out of host memory";
+            return fail(ctx, oom ? RT_ERR_OOM : RT_ERR_SCENE, "rt_upload_scene: %s", ps.lay.error.c_str());
         }
-    });
-
+        ps.nPairs = nPairs;
+        rootCodes = ps.lay.rootCodes; /* final codes from here on (only their leaf bit is read below) */
+    }
     if (getenv("RT_DEBUG_UPLOAD"))
-        fprintf(stderr, "[rt] prepare_scene: triangles re-laid out in %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tConv).count());
+        fprintf(stderr, "[rt] prepare_scene: layout %s (%zu + %zu + %zu bytes) in %.2f ms\n", ps.lay.used.name().c_str(), ps.lay.pairBuf.size(), ps.lay.triBuf.size(),
+                ps.lay.normBuf.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tConv).count());
     pack_spheres(spheres, n_spheres, ps.sph, &ps.sphereBound);
     ps.mats.resize((size_t)n_spheres + n_models);
     for (int i = 0; i < n_spheres; i++) pack_material(spheres[i].material, ps.mats[i]);
     ps.dmodels.resize(n_models);
     for (int i = 0; i < n_models; i++) {
-        pack_model(models[i], rootCodes[i], ps.dmodels[i]);
+        pack_model(models[i], rootCodes[i], ps.lay.triBase[i], ps.dmodels[i]);
         pack_material(models[i].material, ps.mats[n_spheres + i]);
     }
     make_filters(models, n_models, rootCodes, rootChildren, spheres, n_spheres, ps.filters, &ps.maxOrigin);
     make_chunks(ps.filters, ps.chunks, &ps.nFiltered, &ps.extWords);
     ps.filters = append_filter_pairs(ps.filters); /* uploaded as one array */
-    ps.bigLeaves.swap(sb.bigLeaves);
     ps.hModels.assign(models, models + n_models);
     ps.hSpheres.assign(spheres, spheres + n_spheres);
     ps.nTris = n_triangles;
@@ -1220,10 +1197,12 @@ static int commit_scene(RtContext* ctx, const PreparedScene& ps, const RtContext
     if ((rc = commit_vec(ctx, &ctx->dSpheres, ps.sph, peer ? &peer->dSpheres : nullptr, peer))) return rc;
     if ((rc = commit_vec(ctx, &ctx->dMaterials, ps.mats, peer ? &peer->dMaterials : nullptr, peer))) return rc;
     if ((rc = commit_vec(ctx, &ctx->dModels, ps.dmodels, peer ? &peer->dModels : nullptr, peer))) return rc;
-    if ((rc = commit_vec(ctx, &ctx->dPairs, ps.pairs, peer ? &peer->dPairs : nullptr, peer))) return rc;
-    if ((rc = commit_vec(ctx, &ctx->dTris, ps.dtris, peer ? &peer->dTris : nullptr, peer))) return rc;
-    if ((rc = commit_vec(ctx, &ctx->dNorms, ps.dnorms, peer ? &peer->dNorms : nullptr, peer))) return rc;
-    if ((rc = commit_vec(ctx, &ctx->dBigLeaves, ps.bigLeaves, peer ? &peer->dBigLeaves : nullptr, peer))) return rc;
+    if ((rc = commit_vec(ctx, &ctx->dPairs, ps.lay.pairBuf, peer ? &peer->dPairs : nullptr, peer))) return rc;
+    if (!ps.lay.arena && (rc = commit_vec(ctx, &ctx->dTris, ps.lay.triBuf, peer ? &peer->dTris : nullptr, peer))) return rc;
+    if ((rc = commit_vec(ctx, &ctx->dNorms, ps.lay.normBuf, peer ? &peer->dNorms : nullptr, peer))) return rc;
+    if ((rc = commit_vec(ctx, &ctx->dBigLeaves, ps.lay.bigLeaves, peer ? &peer->dBigLeaves : nullptr, peer))) return rc;
+    ctx->arenaLayout = ps.lay.arena;
+    ctx->layoutUsed = ps.lay.used.name();
     if ((rc = commit_vec(ctx, &ctx->dFilters, ps.filters, peer ? &peer->dFilters : nullptr, peer))) return rc;
     if ((rc = commit_vec(ctx, &ctx->dChunks, ps.chunks, peer ? &peer->dChunks : nullptr, peer))) return rc;
     ctx->nChunks = (int)ps.chunks.size();
@@ -1236,7 +1215,8 @@ static int commit_scene(RtContext* ctx, const PreparedScene& ps, const RtContext
     ctx->nSpheres = (int)ps.hSpheres.size();
     ctx->nModels = (int)ps.hModels.size();
     ctx->nTris = ps.nTris;
-    ctx->nPairs = (int)ps.pairs.size();
+    ctx->nPairs = (int)ps.nPairs;
+    ctx->hTriBase = ps.lay.triBase;
     ctx->stackEntries = ps.maxHeight;
     ctx->flatScene = ps.flat;
     ctx->hModels = ps.hModels;
@@ -1268,7 +1248,7 @@ int rt_upload_scene(RtContext* ctx, const RtModel* models, int n_models, const R
     if (getenv("RT_DEBUG_UPLOAD"))
         fprintf(stderr, "[rt] rt_upload_scene: prepare %.2f ms, commit %.2f ms (%d triangles, %zu node pairs)\n",
                 std::chrono::duration<double, std::milli>(t1 - t0).count(),
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(), n_triangles, ps.pairs.size());
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(), n_triangles, ps.nPairs);
     return rc;
 }
 
@@ -1282,13 +1262,43 @@ int rt_validate_scene(const RtModel* models, int n_models, const RtTriangle* tri
         memset(out_info, 0, sizeof(*out_info));
         out_info->prepare_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (rc == RT_OK) {
-            out_info->n_pairs = (int32_t)ps.pairs.size();
+            out_info->n_pairs = (int32_t)ps.nPairs;
             out_info->max_height = ps.maxHeight;
             out_info->flat = ps.flat ? 1 : 0;
             out_info->n_filtered = ps.nFiltered;
         }
     }
     return rc;
+}
+
+int rt_debug_layout(const RtModel* models, int n_models, const RtTriangle* triangles, int n_triangles,
+                    const RtBVHNode* nodes, int n_nodes, const char* layout, RtLayoutDump* out)
+{
+    if (!out) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_debug_layout: null output");
+    memset(out, 0, sizeof(*out));
+    PreparedScene ps;
+    const int rc = prepare_scene(nullptr, models, n_models, triangles, n_triangles, nodes, n_nodes, nullptr, 0, ps, layout);
+    if (rc) return rc;
+    auto take = [](PodVec<unsigned char>& v, unsigned char** p, size_t* n) { *p = v.p; *n = v.n; v.p = nullptr; v.n = 0; };
+    take(ps.lay.pairBuf, &out->pair_space, &out->pair_bytes);
+    take(ps.lay.triBuf, &out->tri_space, &out->tri_bytes);
+    take(ps.lay.normBuf, &out->norm_space, &out->norm_bytes);
+    auto dup = [](const void* src, size_t bytes) { void* q = malloc(bytes ? bytes : 1); if (q && bytes) memcpy(q, src, bytes); return q; };
+    out->n_big_leaves = ps.lay.bigLeaves.size() / 2;
+    out->big_leaves = (uint32_t*)dup(ps.lay.bigLeaves.data(), ps.lay.bigLeaves.size() * 4);
+    out->root_codes = (uint32_t*)dup(ps.lay.rootCodes.data(), ps.lay.rootCodes.size() * 4);
+    out->tri_base = (int32_t*)dup(ps.lay.triBase.data(), ps.lay.triBase.size() * 4);
+    out->n_models = n_models;
+    out->arena = ps.lay.arena ? 1 : 0;
+    snprintf(out->used, sizeof(out->used), "%s", ps.lay.used.name().c_str());
+    return RT_OK;
+}
+
+void rt_debug_layout_free(RtLayoutDump* d)
+{
+    if (!d) return;
+    free(d->pair_space); free(d->tri_space); free(d->norm_space); free(d->big_leaves); free(d->root_codes); free(d->tri_base);
+    memset(d, 0, sizeof(*d));
 }
 
 int rt_update_models(RtContext* ctx, const RtModel* models, int n_models)
@@ -1309,7 +1319,7 @@ int rt_update_models(RtContext* ctx, const RtModel* models, int n_models)
     for (int i = 0; i < n_models; i++) {
         if (models[i].nodeOffset != ctx->hModels[i].nodeOffset || models[i].triOffset != ctx->hModels[i].triOffset)
             return fail(ctx, RT_ERR_INVALID_ARG, "rt_update_models: model %d changed its BVH offsets; re-upload the scene", i);
-        pack_model(models[i], ctx->hRootCodes[i], dmodels[i]);
+        pack_model(models[i], ctx->hRootCodes[i], ctx->hTriBase[i], dmodels[i]);
         pack_material(models[i].material, mats[i]);
         if (memcmp(models[i].worldToLocal, ctx->hModels[i].worldToLocal, sizeof(models[i].worldToLocal)) != 0 ||
             memcmp(models[i].localToWorld, ctx->hModels[i].localToWorld, sizeof(models[i].localToWorld)) != 0)
@@ -1410,9 +1420,9 @@ static void fill_args(RtContext* ctx, int frame0, int nFrames, KArgs& a)
     a.sphereBound = ctx->sphereBound;
     a.materials = ctx->dMaterials;
     a.models = ctx->dModels;
-    a.pairs = ctx->dPairs;
-    a.tris = ctx->dTris;
-    a.norms = ctx->dNorms;
+    a.pairs = reinterpret_cast<const DPair*>(ctx->dPairs);
+    a.tris = reinterpret_cast<const DTri*>(ctx->arenaLayout ? ctx->dPairs : ctx->dTris);
+    a.norms = reinterpret_cast<const DTriN*>(ctx->dNorms);
     a.bigLeaves = ctx->dBigLeaves;
     a.filters = ctx->dFilters;
     a.filterPairs = reinterpret_cast<const float*>(ctx->dFilters + ctx->nModels);
@@ -1786,6 +1796,35 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
 #endif
         a.tileQueue = ctx->dTileQueue + q;
         a.tileQueueBase = ctx->tileQueueNext[q] - (a.queueStart ? 0ull : (unsigned long long)grid);
+#ifdef RT_XCD_EXPERIMENT
+        const bool xcdQ = ctx->xcdAffinity > 0 && staged && !wgActive && !queued;
+#else
+        const bool xcdQ = false;
+#endif
+        if (xcdQ) {
+            if (!ctx->dXcdQueues) HIP_TRY(ctx, hipMalloc(&ctx->dXcdQueues, 16 * sizeof(unsigned long long)));
+            if (ctx->xcdAffinity == 2) {
+                if (ctx->blockOrderTiles != tiles) { /* position -> tile: eight blocks (4 across, 2 down), rows within a block */
+                    std::vector<uint32_t> order;
+                    order.reserve(tiles);
+                    for (int by = 0; by < 2; by++)
+                        for (int bx = 0; bx < 4; bx++) {
+                            const int x0 = a.tilesX * bx / 4, x1 = a.tilesX * (bx + 1) / 4, y0 = a.tilesY * by / 2, y1 = a.tilesY * (by + 1) / 2;
+                            for (int y = y0; y < y1; y++)
+                                for (int x = x0; x < x1; x++) order.push_back((uint32_t)(y * a.tilesX + x));
+                        }
+                    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
+                    hipFree(ctx->dBlockOrder); ctx->dBlockOrder = nullptr;
+                    HIP_TRY(ctx, hipMalloc(&ctx->dBlockOrder, sizeof(uint32_t) * tiles));
+                    HIP_TRY(ctx, hipMemcpy(ctx->dBlockOrder, order.data(), sizeof(uint32_t) * tiles, hipMemcpyHostToDevice));
+                    ctx->blockOrderTiles = tiles;
+                }
+                a.tileOrder = ctx->dBlockOrder;
+            }
+            a.xcdQueues = ctx->dXcdQueues + 8 * q;
+            a.queueStart = 1;
+            HIP_TRY(ctx, hipMemsetAsync(a.xcdQueues, 0, 8 * sizeof(unsigned long long), st));
+        }
         if (ctx->sortPending[q]) { /* the order array this kernel reads was sorted on the other stream */
             HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->evSort, 0));
             ctx->sortPending[q] = false;
@@ -1812,7 +1851,7 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         if (probe) { hipEventRecord(probe->stop, st); probe->live = true; }
         HIP_TRY(ctx, hipGetLastError()); /* a refused launch ran no wave: the device counter did not move */
         /* every tile not taken by blockIdx is one successful fetch, and each of the grid waves overshoots once */
-        ctx->tileQueueNext[q] += (unsigned long long)items + (a.queueStart ? (unsigned long long)grid : 0ull);
+        if (!xcdQ) ctx->tileQueueNext[q] += (unsigned long long)items + (a.queueStart ? (unsigned long long)grid : 0ull);
         if (q == 1) ctx->sideDirty = true;
         if (!staged) {
             const int mrc = mark_acc_writer(q, parts == 1);

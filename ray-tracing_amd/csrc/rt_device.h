@@ -43,9 +43,10 @@
 #define RT_COUNTER_FIELDS (8 + 2 * RT_N_PHASES)
 #endif
 
-/* node codes: bit31 = leaf.  leaf: [30:24] = triangle count (1..127), [23:0] = first
- * triangle (relative to the model's triOffset); count field 0 = indirect, [23:0]
- * indexes bigLeaves {start,count}.  inner: [30:0] = absolute DPair index. */
+/* Every record of the traversal is named by the 16-byte UNIT it starts at (rt_layout.h decides where the records lie):
+ * node codes: bit31 = leaf.  leaf: [30:24] = triangle count (1..127), [23:0] = first unit of the leaf's run of DTri records
+ * (three units each) relative to the model's triBase; count field 0 = indirect, [23:0] indexes bigLeaves {unit, count}.
+ * inner: [30:0] = unit of the DPair in the pair space. */
 #define RT_CODE_LEAF 0x80000000u
 #define RT_CODE_NEXT_MODEL 0x7fffffffu /* traversal state: this model is finished */
 #define RT_CODE_DONE 0x7ffffffeu       /* traversal state: every model visited (inner codes are below this) */
@@ -66,13 +67,13 @@ struct DTri {
 struct DTriN {
     float n[9];
 };
-/* the kernels address these arrays with shifted 32-bit byte offsets (rt_kernels.h: cur << 6, triIndex * 48u) */
+/* the kernels address these records with shifted 32-bit byte offsets (rt_kernels.h: unit << 4) */
 static_assert(sizeof(DPair) == 64 && sizeof(DTri) == 48 && sizeof(DTriN) == 36, "rt_kernels.h hard-codes the record sizes");
 struct DModel {
     float w2l[12]; /* row r: m[r], m[4+r], m[8+r], m[12+r] of worldToLocal */
     float l2w[12];
     uint32_t rootCode;    /* 16-B aligned tail: (rootCode, triBase, cullBackface, -) */
-    int32_t triBase;
+    int32_t triBase;      /* first unit of the model's triangles in the triangle space */
     int32_t cullBackface; /* material.flag != GLASS (RC:355) */
     int32_t pad[5];
 };
@@ -113,10 +114,10 @@ struct KArgs {
     float sphereBound;           /* max_k(|c_k|^2 + r_k^2): scales the pre-test's error margin */
     const DMaterial* materials;  /* [0,nSpheres) spheres, then models */
     const DModel* models;
-    const DPair* pairs;
-    const DTri* tris;
-    const DTriN* norms;
-    const uint32_t* bigLeaves;   /* pairs of (start, count) */
+    const DPair* pairs;          /* the pair space */
+    const DTri* tris;            /* the triangle space (the arena layout: == pairs) */
+    const DTriN* norms;          /* 12 bytes per unit of the triangle space: the normals of the triangle at unit u start at byte 12 u */
+    const uint32_t* bigLeaves;   /* pairs of (first unit, count) */
     const DFilter* filters;      /* one per model */
     const float* filterPairs;    /* the same boxes two models side by side (minx0 minx1 miny0 miny1 minz0 minz1 maxx0 ... always0 always1 - -),
                                   * sixteen dwords per pair, behind the DFilter array: the packed two-models-per-step root filter */
@@ -172,6 +173,10 @@ struct KArgs {
     int32_t queueStart;          /* 1: the first position of every wave comes from the queue too (not blockIdx) */
     unsigned long long* tileQueue;
     unsigned long long tileQueueBase;
+    /* EXPERIMENT (RT_XCD_AFFINITY, profiles/r05_ab_layout.txt): eight counters, zero at launch; the queue positions are cut into eight
+     * contiguous ranges and a wave draws from the range of the XCD it runs on (each XCD has its own L2), from the others' when
+     * its own is used up.  Null = one queue for the chip. */
+    unsigned long long* xcdQueues;
     /* longest-chain-first scheduling: queue position -> tile (null = identity), and the
      * per-tile record of the longest pixel chain seen so far (segments in one frame) */
     const uint32_t* tileOrder;

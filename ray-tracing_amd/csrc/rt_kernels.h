@@ -224,15 +224,29 @@ __device__ __forceinline__ rt_f3 material_colour(const DMaterial& mat, rt_f3 pos
     return rt_lerp3(col, rt_v3(mat.specularCol[0], mat.specularCol[1], mat.specularCol[2]), isSpecular ? 1.0f : 0.0f);
 }
 
+/* EXPERIMENT (make tri-nt): triangle records are the least re-used lines of a BVH scene — fetched with the non-temporal
+ * policy they are the first an L2 gives up, which leaves the room to node pairs (profiles/r05_ab_layout.txt) */
+#ifdef RT_TRI_NT
+typedef float rt_nt4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 rt_load_nt(const float4* p)
+{
+    const rt_nt4 v = __builtin_nontemporal_load(reinterpret_cast<const rt_nt4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+#define RT_TRI_LOAD(q, p, i) const float4 q = rt_load_nt((p) + (i))
+#else
+#define RT_TRI_LOAD(q, p, i) const float4 q = (p)[i]
+#endif
 /* RayTriangle — RC:188-215 on a pre-differenced triangle. Updates the closest
  * hit with the reference's strict '<' (RC:256). */
-__device__ __forceinline__ void tri_test(const DTri* __restrict__ tris, int triIndex, rt_f3 pos, rt_f3 dir, bool cull,
+__device__ __forceinline__ void tri_test(const DTri* __restrict__ tris, int triUnit, rt_f3 pos, rt_f3 dir, bool cull,
                                          float& bestDst, int& bestTri, float& bu, float& bv, float& bdet)
 {
-    /* 32-bit byte offset from the uniform array base (SGPR base + VGPR offset addressing, see the inner step);
-     * rt_upload_scene refuses scenes whose triangle array reaches 4 GiB */
-    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tris) + (uint32_t)triIndex * 48u);
-    float4 q0 = p[0], q1 = p[1], q2 = p[2];
+    /* A triangle is named by the 16-byte UNIT its record starts at (rt_device.h: three units per record, the host's layout
+     * decides where the runs of a leaf lie): a 32-bit byte offset from the uniform array base (SGPR base + VGPR offset
+     * addressing, see the inner step) is one shift; rt_upload_scene refuses scenes whose triangle space reaches 4 GiB */
+    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tris) + ((uint32_t)triUnit << 4));
+    RT_TRI_LOAD(q0, p, 0); RT_TRI_LOAD(q1, p, 1); RT_TRI_LOAD(q2, p, 2);
     rt_f3 A = rt_v3(q0.x, q0.y, q0.z);
     rt_f3 edgeAB = rt_v3(q0.w, q1.x, q1.y);
     rt_f3 edgeAC = rt_v3(q1.z, q1.w, q2.x);
@@ -249,7 +263,7 @@ __device__ __forceinline__ void tri_test(const DTri* __restrict__ tris, int triI
     bool didHit = keep && dst > 0 && u >= 0 && v >= 0 && w >= 0;
     if (didHit && dst < bestDst) {
         bestDst = dst;
-        bestTri = triIndex;
+        bestTri = triUnit;
         bu = u;
         bv = v;
         bdet = determinant;
@@ -409,7 +423,7 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
                     if (count == 0) { count = a.bigLeaves[2 * start + 1]; start = a.bigLeaves[2 * start]; }
                     float best = h.dst, bu, bv, bdet;
                     int btri = -1;
-                    for (uint32_t i = 0; i < count; i++) tri_test(a.tris, M.triBase + (int)start + (int)i, lpos, ldir, M.cullBackface != 0, best, btri, bu, bv, bdet);
+                    for (uint32_t i = 0; i < count; i++) tri_test(a.tris, M.triBase + (int)start + 3 * (int)i, lpos, ldir, M.cullBackface != 0, best, btri, bu, bv, bdet);
                     if (btri >= 0) st.filterViolations++; /* audit: a rejected model must not hold a closer hit */
                 }
                 if ((F.innerRoot & 1u) && !keep) { /* audit the conservative filter against the exact root step */
@@ -421,7 +435,7 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
                                        M.w2l[4] * rdir.x + M.w2l[5] * rdir.y + M.w2l[6] * rdir.z + M.w2l[7] * 0.0f,
                                        M.w2l[8] * rdir.x + M.w2l[9] * rdir.y + M.w2l[10] * rdir.z + M.w2l[11] * 0.0f);
                     rt_f3 linv = rt_v3(rt_rcp(ldir.x), rt_rcp(ldir.y), rt_rcp(ldir.z));
-                    const RT_CAS DPair& P = ((const RT_CAS DPair*)a.pairs)[M.rootCode];
+                    const RT_CAS DPair& P = *(const RT_CAS DPair*)((const RT_CAS char*)a.pairs + ((size_t)M.rootCode << 4));
                     float pa0[3] = {P.aMin[0], P.aMin[1], P.aMin[2]}, pa1[3] = {P.aMax[0], P.aMax[1], P.aMax[2]};
                     float pb0[3] = {P.bMin[0], P.bMin[1], P.bMin[2]}, pb1[3] = {P.bMax[0], P.bMax[1], P.bMax[2]};
                     if (box_dst(lpos, linv, pa0, pa1) < h.dst || box_dst(lpos, linv, pb0, pb1) < h.dst) st.filterViolations++;
@@ -620,10 +634,11 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
                 t.rootStep = false;
                 phase_mark<STATS>(st, PH_INNER);
 #ifndef RT_LDS_NODE_FETCH
-                /* a 32-bit byte offset from the (wave-uniform) array base: the load takes "SGPR base + VGPR offset" and the
-                 * 64-bit shift and add of a full pointer (two slow-class VALU instructions per step on gfx950) become one fast
-                 * 32-bit shift; rt_upload_scene refuses scenes with 2^26 pairs or more */
-                const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pairs) + (uint32_t)(t.cur << 6));
+                /* an inner code is the 16-byte unit the pair record starts at (rt_device.h; the host's layout decides where
+                 * that is): a 32-bit byte offset from the (wave-uniform) array base — the load takes "SGPR base + VGPR offset",
+                 * and the 64-bit shift and add of a full pointer (two slow-class VALU instructions per step on gfx950) become
+                 * one fast 32-bit shift; rt_upload_scene refuses scenes whose pair space reaches 4 GiB */
+                const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pairs) + (uint32_t)(t.cur << 4));
                 const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3]; /* (loading only the 8 bytes of q3 that are used changes nothing: 9.9) */
 #else
                 /* EXPERIMENT kept reproducible (make lds-fetch; profiles/r02_lds_node_fetch.txt): the north_star's
@@ -633,7 +648,7 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
                  * measured slower: the kernel is VALU-issue bound (profiles/r02_occupancy_sweep.txt), the fetch is a
                  * dependent pointer chase with nothing to overlap, and the slab costs 4 KB of LDS per wave. */
                 {
-                    const char* g = reinterpret_cast<const char*>(pairs + t.cur);
+                    const char* g = reinterpret_cast<const char*>(pairs) + ((size_t)t.cur << 4);
                     for (int qq = 0; qq < 4; qq++)
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 16 * qq),
                                                          (__attribute__((address_space(3))) void*)(nodeSlab + qq * RT_WAVE * 4), 16, 0, 0);
@@ -649,8 +664,8 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
                 /* EXPERIMENT (make child-prefetch): touch one dword of each child's record (the pair of an inner child, the first
                  * triangle of a leaf child) as soon as the codes are known, so that the line is on its way while the box tests run */
                 {
-                    const uint32_t offA = (codeA & RT_CODE_LEAF) ? (uint32_t)(t.triBase + (int)(codeA & RT_CODE_MAX_INLINE_START)) * (uint32_t)sizeof(DTri) : codeA << 6;
-                    const uint32_t offB = (codeB & RT_CODE_LEAF) ? (uint32_t)(t.triBase + (int)(codeB & RT_CODE_MAX_INLINE_START)) * (uint32_t)sizeof(DTri) : codeB << 6;
+                    const uint32_t offA = (codeA & RT_CODE_LEAF) ? (uint32_t)(t.triBase + (int)(codeA & RT_CODE_MAX_INLINE_START)) << 4 : codeA << 4;
+                    const uint32_t offB = (codeB & RT_CODE_LEAF) ? (uint32_t)(t.triBase + (int)(codeB & RT_CODE_MAX_INLINE_START)) << 4 : codeB << 4;
                     const char* baseA = (codeA & RT_CODE_LEAF) ? reinterpret_cast<const char*>(tris) : reinterpret_cast<const char*>(pairs);
                     const char* baseB = (codeB & RT_CODE_LEAF) ? reinterpret_cast<const char*>(tris) : reinterpret_cast<const char*>(pairs);
                     uint32_t ta, tb;
@@ -688,7 +703,7 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
             for (uint32_t i = 0; i < count; i++) {
                 phase_mark<STATS>(st, PH_TRI);
                 const float before = h.dst;
-                tri_test(tris, first + (int)i, t.lpos, t.ldir, t.cull, h.dst, h.tri, h.u, h.v, h.det);
+                tri_test(tris, first + 3 * (int)i, t.lpos, t.ldir, t.cull, h.dst, h.tri, h.u, h.v, h.det);
                 if (h.dst < before) { /* RC:362-369 (an update strictly lowers dst) */
                     h.obj = a.nSpheres + t.m;
                     h.backface = h.det < 0;
@@ -733,7 +748,7 @@ __device__ __forceinline__ void traverse_flat(const KArgs& a, rt_f3 rpos, rt_f3 
         for (uint32_t i = 0; i < count; i++) {
             phase_mark<STATS>(st, PH_TRI);
             const float before = h.dst;
-            tri_test(tris, first + (int)i, lpos, ldir, cull, h.dst, h.tri, h.u, h.v, h.det);
+            tri_test(tris, first + 3 * (int)i, lpos, ldir, cull, h.dst, h.tri, h.u, h.v, h.det);
             if (h.dst < before) {
                 h.obj = a.nSpheres + m;
                 h.backface = h.det < 0;
@@ -767,7 +782,8 @@ __device__ __forceinline__ void resolve_hit(const KArgs& a, rt_f3 rpos, rt_f3 rd
         normal = rt_normalize(hpos - centre) * (h.backface ? -1.0f : 1.0f);
     } else {
         const DModel& M = a.models[h.obj - a.nSpheres];
-        const DTriN& N = a.norms[h.tri];
+        /* the winner's vertex normals: 12 bytes per unit of the triangle space, i.e. the 36-byte record of the triangle at unit h.tri */
+        const DTriN& N = *reinterpret_cast<const DTriN*>(reinterpret_cast<const char*>(a.norms) + (uint32_t)h.tri * 12u);
         float w = 1 - h.u - h.v;
         rt_f3 sn = rt_normalize(rt_v3(N.n[0], N.n[1], N.n[2]) * w + rt_v3(N.n[3], N.n[4], N.n[5]) * h.u
                                 + rt_v3(N.n[6], N.n[7], N.n[8]) * h.v);
@@ -846,6 +862,9 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
         }                                                       \
     } while (0)
     bool queueEmpty;
+#ifdef RT_XCD_EXPERIMENT
+    uint32_t xcdEmpty = 0; /* KArgs::xcdQueues: ranges this wave has seen used up */
+#endif
     /* wave-uniform, once per tile: every row of an 8-row tile lies in one strip (stripRows % 8 == 0);
      * cyclic strips: local strip ls is global strip ls*partCount + partIndex */
 #define RT_SET_POOL(c, tile)                                                                              \
@@ -924,8 +943,30 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
             if (poolPos >= 64) {
                 if (queueEmpty) break;
                 int next = 0;
-                if (lane == 0) next = (int)(atomicAdd(c.tileQueue, 1ull) - c.tileQueueBase);
-                next = __builtin_amdgcn_readfirstlane(next);
+#ifdef RT_XCD_EXPERIMENT
+                if (c.xcdQueues) { /* EXPERIMENT (make xcd; KArgs::xcdQueues): the range of this wave's XCD first, then the others' */
+                    int got = c.launchItems;
+                    uint32_t emptyNow = xcdEmpty;
+                    if (lane == 0) {
+                        uint32_t xcc;
+                        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                        for (int k = 0; k < 8 && got == c.launchItems; k++) {
+                            const int r = (int)((xcc + (uint32_t)k) & 7u);
+                            if ((emptyNow >> r) & 1u) continue;
+                            const long long lo = (long long)c.launchItems * r / 8, hi = (long long)c.launchItems * (r + 1) / 8;
+                            const unsigned long long pos = atomicAdd(c.xcdQueues + r, 1ull);
+                            if ((long long)pos < hi - lo) got = (int)(lo + (long long)pos);
+                            else emptyNow |= 1u << r;
+                        }
+                    }
+                    next = __builtin_amdgcn_readfirstlane(got);
+                    xcdEmpty = __builtin_amdgcn_readfirstlane(emptyNow);
+                } else
+#endif
+                {
+                    if (lane == 0) next = (int)(atomicAdd(c.tileQueue, 1ull) - c.tileQueueBase);
+                    next = __builtin_amdgcn_readfirstlane(next);
+                }
                 if (next >= c.launchItems) { queueEmpty = true; break; }
                 {
                     const int q_ = next;

@@ -30,14 +30,14 @@ def max_local_rows(world, height, strip_rows=STRIP_ROWS):
     return max(len(global_rows_of(r, world, height, strip_rows)) for r in range(world))
 
 
-def gather_image(local, rank, world, height, dst=0, strip_rows=STRIP_ROWS, group=None):
+def gather_image(local, rank, world, height, dst=0, strip_rows=STRIP_ROWS, group=None, always_collective=False):
     """Gather the packed per-rank row tiles (torch tensors [rows_r, W, 4]) into the full
     [H, W, 4] image on `dst` (returns None elsewhere).  One collective; ranks with
     fewer rows are padded to the common size."""
     import torch
     import torch.distributed as dist
 
-    if world == 1:
+    if world == 1 and not always_collective:  # (always_collective: a one-rank job still runs the gather — bench.py, RT_BENCH_FORCE_DIST)
         return local
     width = local.shape[1]
     pad_rows = max_local_rows(world, height, strip_rows)
@@ -59,7 +59,8 @@ class TiledTracer:
     """A HipTracer restricted to this rank's strips, rendering into torch tensors so the
     tiles can be handed to RCCL without a copy."""
 
-    def __init__(self, tracer, rank, world, device):
+    def __init__(self, tracer, rank, world, device, always_collective=False):
+        self.always_collective = always_collective
         self.tracer = tracer
         self.rank = rank
         self.world = world
@@ -82,4 +83,4 @@ class TiledTracer:
         comm_device: where the collective runs (default: the tiles' own device, i.e. RCCL)."""
         self.tracer.synchronize()
         local = self.accum_t if comm_device is None or comm_device == self.accum_t.device else self.accum_t.to(comm_device)
-        return gather_image(local, self.rank, self.world, height, dst)
+        return gather_image(local, self.rank, self.world, height, dst, always_collective=self.always_collective)

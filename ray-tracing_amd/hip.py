@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "rt_write_accumulated", "rt_timer_begin", "rt_timer_end",
     "rt_enable_stats", "rt_reset_counters", "rt_get_counters", "rt_build_bvh", "rt_build_bvh_mt", "rt_build_bvh_gpu", "rt_build_bvh_gpu_release", "rt_camera_view_params", "rt_version",
     "rt_debug_intersect", "rt_debug_math_eval", "rt_debug_phase_profile", "rt_build_bvh_gpu_batch",
-    "rt_flush", "rt_validate_scene",
+    "rt_flush", "rt_validate_scene", "rt_debug_layout", "rt_debug_layout_free",
     "rt_create_multi", "rt_destroy_multi", "rt_multi_count", "rt_multi_context", "rt_multi_resize", "rt_multi_upload_scene",
     "rt_multi_update_models", "rt_multi_update_spheres", "rt_multi_set_params", "rt_multi_reset_accumulation",
     "rt_multi_render_frame", "rt_multi_render_frames", "rt_multi_synchronize", "rt_gather_accumulated", "rt_gather_frame",
@@ -52,6 +52,8 @@ class HipApi(abi.CApi):
         "build_bvh_gpu_batch": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
         "validate_scene": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+        "debug_layout": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p]),
+        "debug_layout_free": (None, [C.c_void_p]),
         "debug_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
         "debug_math_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
         "debug_phase_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -101,6 +103,35 @@ class HipApi(abi.CApi):
         if rc != abi.RT_OK:
             raise abi.RtError(rc, (self.last_error(None) or b"").decode(errors="replace"))
         return {k: getattr(info, k) for k, _ in _Info._fields_}
+
+    def layout_arrays(self, models, triangles, nodes, layout=None):
+        """rt_debug_layout: the device-memory layout rt_upload_scene would produce (no device needed), as numpy copies:
+        {pair_space, tri_space (None: arena), norm_space (uint8), big_leaves (n,2), root_codes, tri_base, arena, used}."""
+        m, nm = abi._ptr(models, abi.model_dtype)
+        t, nt = abi._ptr(triangles, abi.triangle_dtype)
+        n, nn = abi._ptr(nodes, abi.node_dtype)
+
+        class _Dump(C.Structure):
+            _fields_ = [("pair_space", C.c_void_p), ("pair_bytes", C.c_size_t), ("tri_space", C.c_void_p), ("tri_bytes", C.c_size_t),
+                        ("norm_space", C.c_void_p), ("norm_bytes", C.c_size_t), ("big_leaves", C.c_void_p), ("n_big_leaves", C.c_size_t),
+                        ("root_codes", C.c_void_p), ("tri_base", C.c_void_p), ("n_models", C.c_int32), ("arena", C.c_int32), ("used", C.c_char * 64)]
+        d = _Dump()
+        rc = self.debug_layout(m.ctypes.data if nm else None, nm, t.ctypes.data if nt else None, nt, n.ctypes.data if nn else None, nn,
+                               layout.encode() if layout is not None else None, C.byref(d))
+        if rc != abi.RT_OK:
+            raise abi.RtError(rc, (self.last_error(None) or b"").decode(errors="replace"))
+
+        def arr(ptr, count, dtype):
+            if not ptr or not count:
+                return np.zeros(0, dtype=dtype)
+            return np.frombuffer((C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr), dtype=dtype).copy()
+        try:
+            return {"pair_space": arr(d.pair_space, d.pair_bytes, np.uint8), "tri_space": None if d.arena else arr(d.tri_space, d.tri_bytes, np.uint8),
+                    "norm_space": arr(d.norm_space, d.norm_bytes, np.uint8), "big_leaves": arr(d.big_leaves, 2 * d.n_big_leaves, np.uint32).reshape(-1, 2),
+                    "root_codes": arr(d.root_codes, d.n_models, np.uint32), "tri_base": arr(d.tri_base, d.n_models, np.int32),
+                    "arena": bool(d.arena), "used": d.used.decode()}
+        finally:
+            self.debug_layout_free(C.byref(d))
 
     def build_bvh_arrays_mt(self, verts, normals, indices, quality=abi.BVH_QUALITY_HIGH, threads=0):
         """rt_build_bvh_mt: same output as build_bvh_arrays, on `threads` host threads."""

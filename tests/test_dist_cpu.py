@@ -18,3 +18,30 @@ def test_row_tiled_render_equals_single(world, cfg):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "DIST_OK" in p.stdout
+
+
+def test_one_rank_job_still_runs_the_collective():
+    """gather_image(always_collective=True) at world size 1 (bench.py's RT_BENCH_FORCE_DIST hook, which puts RCCL's gather under
+    test on a 1-GPU box): the collective runs and the de-interleave returns the tile unchanged."""
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {os.path.dirname(HERE)!r})\n"
+        "import __graft_entry__ as g\n"
+        "pkg = g.load_package()\n"
+        "dist.init_process_group('gloo', rank=0, world_size=1)\n"
+        "t = torch.arange(37 * 5 * 4, dtype=torch.float32).reshape(37, 5, 4)\n"
+        "calls = []\n"
+        "real = dist.gather\n"
+        "def spy(*a, **k):\n"
+        "    calls.append(1)\n"
+        "    return real(*a, **k)\n"
+        "dist.gather = spy\n"
+        "out = pkg.dist.gather_image(t, 0, 1, 37, always_collective=True)\n"
+        "assert calls == [1] and out is not t and torch.equal(out, t)\n"
+        "assert pkg.dist.gather_image(t, 0, 1, 37) is t and calls == [1]\n"
+        "dist.destroy_process_group()\n"
+        "print('ONE_RANK_OK')\n")
+    port = 29500 + (os.getpid() + 7) % 2000
+    env = dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and "ONE_RANK_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]

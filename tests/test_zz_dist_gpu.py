@@ -116,6 +116,25 @@ def test_bench_two_gpus_over_rccl():
 
 
 @pytest.mark.gpu
+def test_bench_one_rank_through_rccl():
+    """Everything the driver's SCALE run does that a 1-GPU box can execute, on backend "nccl" (= RCCL): a ONE-rank job forced down
+    the distributed path (RT_BENCH_FORCE_DIST=1) — init_process_group("nccl", device_id=...), the NUMA pinning, partition 1/1 with
+    bound render targets, dist.gather of device tensors + the de-interleave, all_reduce on device tensors, all_gather_object,
+    barrier, destroy — and the gathered image equals the oracle's."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", RT_BENCH_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RT_BENCH_ONE_DEVICE", "RT_BENCH_BACKEND", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline", "--no-pmc", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, _report(p)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, _report(p)
+    d = json.loads(lines[0])
+    _check_multi_rank_line(d, 1, 3, [1920, 1080])
+    assert d["devices_seen"][0]["backend"] == "nccl"
+
+
+@pytest.mark.gpu
 def test_multi_context_peer_access_is_reported(pkg, api):
     """rt_create_multi checks / enables peer access between its distinct devices and says how device-to-device copies travel."""
     import ctypes as C
