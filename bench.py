@@ -171,33 +171,55 @@ def cpu_baseline_reference(pkg, scene_id, width, height, min_s=8.0, max_frames=2
 
 def parity_check(pkg, api, dev_index, scene_id, width, height, strips):
     """In-run parity: frame 1 of the benchmarked scene at the benchmarked size on a fresh context, 8-row
-    strips re-rendered by the oracle — bitwise comparison + per-channel relative L2 of the strips."""
+    strips re-rendered by the oracle — bitwise comparison + per-channel relative L2 of the strips — and, where the library
+    travelled, by the REFERENCE'S OWN TEXT: oracle/_ref/libref.so for a model-only scene, libref_spheres.so (that text + the one
+    declared sphere hook of oracle/make_ref.py) for a scene with analytic spheres, i.e. the headline config."""
     import numpy as np
     tr = api.create_tracer(dev_index)
-    mgr = pkg.scenes.get(scene_id).make_manager(tr, api, width, height)
+    scene = pkg.scenes.get(scene_id)
+    mgr = scene.make_manager(tr, api, width, height)
     mgr.OnEnable(renderSeed=1)
     mgr.RenderFrame()
     gpu = tr.read_accumulated()
     tr.close()
-    orc = graft.load_oracle()
-    c = orc.create_tracer(min(os.cpu_count() or 1, 16))
-    m2 = pkg.scenes.get(scene_id).make_manager(c, orc, width, height)
-    m2.OnEnable(renderSeed=1)
-    for s in strips:
-        m2.numAccumulatedFrames = 1
-        m2.SetShaderParams()
-        orc.set_row_window(c.h, s * 8, min(height, s * 8 + 8))
-        c.render_frame()
-    cpu = c.read_accumulated()
-    c.close()
     rows = np.concatenate([np.arange(s * 8, min(height, s * 8 + 8)) for s in strips])
-    a, b = gpu[rows], cpu[rows]
-    ident = bool(np.array_equal(a.view(np.uint32), b.view(np.uint32)))
-    l2 = [float(np.sqrt(np.sum((a[..., k].astype(np.float64) - b[..., k]) ** 2) / max(float(np.sum(b[..., k].astype(np.float64) ** 2)), 1e-300)))
-          for k in range(3)]
-    mx = float(np.max(np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b.astype(np.float64)), 1e-30)))
-    return {"checked_in_this_run": f"frame 1 at {width}x{height}, 8-row strips {list(strips)} vs oracle/ ({len(rows) * width} pixels)",
-            "bit_identical": ident, "rel_l2_per_channel": l2, "max_rel_err": mx}
+    orc = graft.load_oracle()
+
+    def strips_of(lib, threads):
+        c = lib.create_tracer(threads)
+        m2 = pkg.scenes.get(scene_id).make_manager(c, orc, width, height)  # (BVHs from the oracle's builder either way)
+        m2.OnEnable(renderSeed=1)
+        for s in strips:
+            m2.numAccumulatedFrames = 1
+            m2.SetShaderParams()
+            lib.set_row_window(c.h, s * 8, min(height, s * 8 + 8))
+            c.render_frame()
+        img = c.read_accumulated()
+        c.close()
+        return img[rows]
+
+    def compare(a, b):
+        ident = bool(np.array_equal(a.view(np.uint32), b.view(np.uint32)))
+        l2 = [float(np.sqrt(np.sum((a[..., k].astype(np.float64) - b[..., k]) ** 2) / max(float(np.sum(b[..., k].astype(np.float64) ** 2)), 1e-300)))
+              for k in range(3)]
+        mx = float(np.max(np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b.astype(np.float64)), 1e-30)))
+        return ident, l2, mx
+
+    ident, l2, mx = compare(gpu[rows], strips_of(orc, min(os.cpu_count() or 1, 16)))
+    out = {"checked_in_this_run": f"frame 1 at {width}x{height}, 8-row strips {list(strips)} vs oracle/ ({len(rows) * width} pixels)",
+           "bit_identical": ident, "rel_l2_per_channel": l2, "max_rel_err": mx}
+    try:
+        variant = "spheres" if scene.spheres else ""
+        ref = graft.load_ref(variant)   # raises when the travelling library is stale against oracle/REF_EXPECTED.json
+        if ref is not None:
+            ri, rl2, rmx = compare(gpu[rows], strips_of(ref, min(os.cpu_count() or 1, 64)))
+            out["vs_reference_text"] = {
+                "library": "oracle/_ref/" + ("libref_spheres.so (the reference's HLSL text + the declared sphere hook, make_ref.py S1)" if variant
+                                             else "libref.so (the reference's HLSL text compiled as C++)"),
+                "same_strips": True, "bit_identical": ri, "rel_l2_per_channel": rl2, "max_rel_err": rmx}
+    except Exception as e:  # the oracle comparison above stands; say why the reference-text leg is missing
+        out["vs_reference_text"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 
 def oracle_strips_check(pkg, scene_id, width, height, image, frames, strips):

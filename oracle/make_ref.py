@@ -11,6 +11,13 @@ translation unit for inspection (outside the repo, e.g. /tmp).
 
     python oracle/make_ref.py            # libref.so      (the contract of include/rt_math.h)
     python oracle/make_ref.py --ieee     # libref_ieee.so (-DRT_MATH_IEEE, the other reading of '/', normalize, smoothstep)
+    python oracle/make_ref.py --spheres  # libref_spheres.so: the same text plus ONE declared SEMANTIC rewrite (S1 below) that revives
+                                         # the reference's own RaySphere behind the call it left commented out (RC:341)
+
+Every build also writes oracle/_ref/MANIFEST.json: sha256 of each reference source read, of this recipe and its headers, and of each
+library built.  oracle/REF_EXPECTED.json (committed: hashes, not text) holds the source / recipe hashes the travelling libraries
+must have been built from; tests/test_gpu_ref_pin.py and __graft_entry__.smoke() FAIL when they disagree (a stale prebuilt library
+on the GPU box, which cannot rebuild it).  `--write-expected` refreshes REF_EXPECTED.json after a deliberate change.
 
 tests/test_ref_pin.py compares liboracle.so with libref.so bit for bit.
 """
@@ -69,6 +76,9 @@ def rewrite(text):
     """
     lines = text.split("\n")
     lines = [ln for ln in lines if not re.match(r"\s*#\s*(pragma|include)\b", ln)]                          # 1
+    other = [ln for ln in lines if re.match(r"\s*#", ln)]
+    if other:  # the text is compiled to native code and loaded: no other preprocessor directive gets through unread
+        raise SystemExit("reference shader text: unexpected preprocessor directive %r — review oracle/make_ref.py" % other[0].strip())
     text = "\n".join(lines)
     text = re.sub(r"\[numthreads\([^)]*\)\]", "", text)                                                      # 2
     text = re.sub(r"\s*:\s*SV_DispatchThreadID", "", text)                                                   # 2
@@ -91,13 +101,130 @@ def rewrite(text):
     return text
 
 
-def translation_unit():
+# ---- S1: the one SEMANTIC rewrite (libref_spheres.so only).  The reference keeps RaySphere (RC:289-332) but its only call is the
+# commented line RC:341 with a hard-coded sphere and a hard-coded material (RC:321-327).  S1 replaces that comment by a loop over a
+# sphere buffer that calls the reference's own RaySphere, untouched, and substitutes the sphere's material for the hard-coded one —
+# tested before the model loop with the closest-so-far carried in result.dst, as the commented call's position implies
+# (SURVEY.md 8(a) S1).  These lines are the builder's; everything else of the library is the reference's text.  Written in HLSL so
+# that the syntactic rewrites 1-11 apply to them like to any other line.
+S1_COMMENTED_CALL = "    //result = RaySphere(worldRay.origin, worldRay.dir, float3(0, 1.8, 0), 1);\n"
+S1_HOOK = """    for (int sphereIndex = 0; sphereIndex < sphereCount; sphereIndex++)
+    {
+        Sphere sphere = Spheres[sphereIndex];
+        ModelHitInfo sphereHit = RaySphere(worldRay.pos, worldRay.dir, sphere.centre, sphere.radius);
+        if (sphereHit.didHit && sphereHit.dst < result.dst)
+        {
+            result = sphereHit;
+            result.material = sphere.material;
+        }
+    }
+"""
+S1_DECL_BEFORE = "ModelHitInfo CalculateRayCollision(Ray worldRay, bool forceDontCullBack)\n"
+S1_DECL = """struct Sphere
+{
+    float3 centre;
+    float radius;
+    RayTracingMaterial material;
+};
+StructuredBuffer<Sphere> Spheres;
+int sphereCount;
+
+"""
+
+
+def apply_s1(text):
+    if text.count(S1_COMMENTED_CALL) != 1 or text.count(S1_DECL_BEFORE) != 1:
+        raise SystemExit("RayCommon.hlsl: the commented RaySphere call (RC:341) was not found exactly once — the reference changed, review S1")
+    text = text.replace(S1_DECL_BEFORE, S1_DECL + S1_DECL_BEFORE)
+    return text.replace(S1_COMMENTED_CALL, S1_HOOK)
+
+
+def translation_unit(spheres=False):
     parts = []
     for name in SOURCES:
         with open(os.path.join(SHADER_DIR, name), "r", encoding="utf-8-sig") as f:
-            parts.append("/* ---- %s ---- */\n%s" % (name, rewrite(f.read().replace("\r\n", "\n"))))
+            text = f.read().replace("\r\n", "\n")
+            if spheres and name == "RayCommon.hlsl":
+                text = apply_s1(text)
+            parts.append("/* ---- %s ---- */\n%s" % (name, rewrite(text)))
     return ('#include "%s"\nnamespace hlsl_ref {\n%s\n} /* namespace hlsl_ref */\n#include "%s"\n'
             % (os.path.join(HERE, "ref_compat.h"), "\n".join(parts), os.path.join(HERE, "ref_driver.h")))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MANIFEST.json / REF_EXPECTED.json: what the libraries under oracle/_ref/ were built from
+import hashlib
+import json
+
+RECIPE_FILES = ("make_ref.py", "ref_compat.h", "ref_driver.h", "ref_bvh_compat.h", "ref_bvh_driver.h", "../include/rt_math.h", "../include/rt_abi.h")
+MANIFEST = os.path.join(OUT_DIR, "MANIFEST.json")
+EXPECTED = os.path.join(HERE, "REF_EXPECTED.json")
+
+
+def _sha(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()
+
+
+def input_hashes():
+    """sha256 of every input of the libraries: the reference sources where they lie, the recipe and its headers"""
+    out = {"reference": {}, "recipe": {}}
+    for name in SOURCES:
+        out["reference"][name] = _sha(os.path.join(SHADER_DIR, name))
+    if bvh_available():
+        out["reference"]["BVH.cs"] = _sha(BVH_SOURCE)
+    for name in RECIPE_FILES:
+        out["recipe"][os.path.basename(name)] = _sha(os.path.join(HERE, name))
+    return out
+
+
+def recipe_hashes_here():
+    """the recipe half of input_hashes(): computable anywhere (the GPU box has the recipe, not the reference)"""
+    return {os.path.basename(name): _sha(os.path.join(HERE, name)) for name in RECIPE_FILES}
+
+
+def write_manifest(built):
+    """called after every build: merge the libraries just built into MANIFEST.json under the inputs they were built from"""
+    man = {}
+    if os.path.exists(MANIFEST):
+        try:
+            man = json.load(open(MANIFEST))
+        except Exception:
+            man = {}
+    inputs = input_hashes()
+    if man.get("inputs") != inputs:  # other inputs than last time: whatever else lies in _ref/ is no longer vouched for
+        man = {"inputs": inputs, "libraries": {}}
+    for path in built:
+        man["libraries"][os.path.basename(path)] = _sha(path)
+    with open(MANIFEST, "w") as f:
+        json.dump(man, f, indent=1, sort_keys=True)
+
+
+def check_manifest(libraries):
+    """None when oracle/_ref/<libraries> are what MANIFEST.json says AND MANIFEST.json's inputs are REF_EXPECTED.json's AND the
+    recipe files in this tree are the ones they were built with; else a sentence saying what is stale."""
+    if not os.path.exists(EXPECTED):
+        return "oracle/REF_EXPECTED.json is missing"
+    if not os.path.exists(MANIFEST):
+        return "oracle/_ref/MANIFEST.json is missing: rebuild with `python oracle/make_ref.py --all` where /root/reference exists"
+    man, exp = json.load(open(MANIFEST)), json.load(open(EXPECTED))
+    if man.get("inputs") != exp.get("inputs"):
+        diff = [k for sec in ("reference", "recipe") for k in set(man.get("inputs", {}).get(sec, {})) | set(exp.get("inputs", {}).get(sec, {}))
+                if man.get("inputs", {}).get(sec, {}).get(k) != exp.get("inputs", {}).get(sec, {}).get(k)]
+        return "oracle/_ref was built from other inputs than oracle/REF_EXPECTED.json names: " + ", ".join(sorted(diff))
+    here = recipe_hashes_here()
+    stale = sorted(k for k, v in here.items() if exp["inputs"]["recipe"].get(k) != v)
+    if stale:
+        return "recipe files changed since oracle/_ref was built (rebuild, then `make_ref.py --write-expected`): " + ", ".join(stale)
+    for name in libraries:
+        path = os.path.join(OUT_DIR, name)
+        if not os.path.exists(path):
+            return "oracle/_ref/%s is missing" % name
+        if man.get("libraries", {}).get(name) != _sha(path):
+            return "oracle/_ref/%s is not the file MANIFEST.json describes" % name
+    return None
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -232,6 +359,7 @@ def build_bvh(emit=None, quiet=False):
     out = os.path.join(OUT_DIR, "libref_bvh.so")
     cmd = [os.environ.get("CXX", "g++")] + CXXFLAGS + ["-I", HERE, "-shared", "-o", out, "-x", "c++", "-"]
     subprocess.run(cmd, input=tu.encode(), check=True, stdout=subprocess.DEVNULL if quiet else None)
+    write_manifest([out])
     return out
 
 
@@ -239,20 +367,21 @@ def available():
     return all(os.path.exists(os.path.join(SHADER_DIR, s)) for s in SOURCES)
 
 
-def build(ieee=False, emit=None, quiet=False):
+def build(ieee=False, emit=None, quiet=False, spheres=False):
     if not available():
         raise FileNotFoundError("reference shader sources not found under %s" % SHADER_DIR)
-    tu = translation_unit()
+    tu = translation_unit(spheres=spheres)
     if emit:
         if os.path.abspath(emit).startswith(os.path.dirname(HERE) + os.sep):
             raise SystemExit("--emit inside the repository would copy reference text into it: choose a path outside")
         with open(emit, "w") as f:
             f.write(tu)
     os.makedirs(OUT_DIR, exist_ok=True)
-    out = os.path.join(OUT_DIR, "libref_ieee.so" if ieee else "libref.so")
-    cmd = [os.environ.get("CXX", "g++")] + CXXFLAGS + (["-DRT_MATH_IEEE"] if ieee else []) + \
+    out = os.path.join(OUT_DIR, "libref_spheres.so" if spheres else "libref_ieee.so" if ieee else "libref.so")
+    cmd = [os.environ.get("CXX", "g++")] + CXXFLAGS + (["-DRT_MATH_IEEE"] if ieee else []) + (["-DREF_SPHERES"] if spheres else []) + \
         ["-I", HERE, "-shared", "-o", out, "-x", "c++", "-"]
     subprocess.run(cmd, input=tu.encode(), check=True, stdout=subprocess.DEVNULL if quiet else None)
+    write_manifest([out])
     return out
 
 
@@ -262,15 +391,36 @@ if __name__ == "__main__":
     ap.add_argument("--both", action="store_true")
     ap.add_argument("--emit")
     ap.add_argument("--bvh", action="store_true", help="build oracle/_ref/libref_bvh.so (BVH.cs) instead of the shader library")
+    ap.add_argument("--spheres", action="store_true", help="build oracle/_ref/libref_spheres.so (the shader text + the declared semantic rewrite S1)")
+    ap.add_argument("--all", action="store_true", help="libref.so, libref_ieee.so, libref_spheres.so, libref_bvh.so")
+    ap.add_argument("--write-expected", action="store_true", help="record the present source / recipe hashes in oracle/REF_EXPECTED.json")
+    ap.add_argument("--check", action="store_true", help="exit 1 with a sentence when oracle/_ref is stale against REF_EXPECTED.json")
     ap.add_argument("--if-available", action="store_true", help="exit 0 quietly when /root/reference is absent (GPU box)")
     a = ap.parse_args()
     if a.if_available and not available():
         print("make_ref: %s absent — keeping whatever oracle/_ref/ holds" % SHADER_DIR)
         sys.exit(0)
+    if a.check:
+        why = check_manifest(["libref.so", "libref_ieee.so", "libref_spheres.so", "libref_bvh.so"])
+        print(why or "oracle/_ref is what oracle/REF_EXPECTED.json names")
+        sys.exit(1 if why else 0)
+    if a.write_expected:
+        with open(EXPECTED, "w") as f:
+            json.dump({"what": "sha256 of the inputs oracle/_ref/*.so must have been built from (reference sources as they lie under "
+                               "/root/reference, this recipe and its headers); hashes, not text — see make_ref.py",
+                       "inputs": input_hashes()}, f, indent=1, sort_keys=True)
+        print("wrote", EXPECTED)
+        sys.exit(0)
     if a.bvh:
         print("built", build_bvh(emit=a.emit))
         sys.exit(0)
-    for ieee in ((False, True) if a.both else (a.ieee,)):
+    if a.spheres:
+        print("built", build(spheres=True, emit=a.emit))
+        sys.exit(0)
+    both = a.both or a.all
+    for ieee in ((False, True) if both else (a.ieee,)):
         print("built", build(ieee=ieee, emit=a.emit))
-    if a.both and bvh_available():
+    if a.all:
+        print("built", build(spheres=True))
+    if both and bvh_available():
         print("built", build_bvh())

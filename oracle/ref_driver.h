@@ -10,7 +10,9 @@
  *   ref_reset_accumulation≙ Dispatch(ResetAccumulated)                                         RCM:69-76, RCC:26-32
  * plus function-level entry points so that every reference function can be compared with the oracle's restatement
  * on its own.  The reference has no sphere buffer (RaySphere's only call is commented out, RC:341): scenes with
- * analytic spheres are refused, RaySphere itself is exposed at function level.
+ * analytic spheres are refused, RaySphere itself is exposed at function level.  -DREF_SPHERES (libref_spheres.so,
+ * make_ref.py --spheres): the translation unit carries the declared semantic rewrite S1 — a `Spheres` buffer tested in
+ * front of the model loop through the reference's own RaySphere — and this file binds that buffer.
  */
 #include <atomic>
 #include <mutex>
@@ -33,15 +35,20 @@ static_assert(sizeof(Model) == sizeof(RtModel) && sizeof(RtModel) == 224, "RC:78
 static_assert(sizeof(Triangle) == sizeof(RtTriangle) && sizeof(RtTriangle) == 72, "RC:49-53");
 static_assert(sizeof(BVHNode) == sizeof(RtBVHNode) && sizeof(RtBVHNode) == 32, "RC:87-95");
 static_assert(sizeof(float4) == 16 && sizeof(float4x4) == 64, "texel / matrix");
+#ifdef REF_SPHERES
+static_assert(sizeof(Sphere) == sizeof(RtSphere) && sizeof(RtSphere) == 104, "S1: float3 centre, float radius, RayTracingMaterial");
+#endif
 
 struct RefContext {
     std::vector<RtModel> models;
     std::vector<RtTriangle> triangles;
     std::vector<RtBVHNode> nodes;
+    std::vector<RtSphere> spheres;
     std::vector<float4> frameRender, accumulated;
     RtParams params = {};
     bool haveParams = false;
     int W = 0, H = 0, frame = 1, threads = 1;
+    int rowBegin = -1, rowEnd = -1; /* ref_set_row_window: dispatch only the thread ids of these rows (checkers of large images) */
     int64_t triTests = 0, boxTests = 0, segments = 0;
     uint64_t pixelFrames = 0;
     char err[256] = {0};
@@ -86,6 +93,11 @@ void bind(RefContext* c)
     Triangles.count = (int64_t)c->triangles.size();
     Nodes.data = reinterpret_cast<const BVHNode*>(c->nodes.data());
     Nodes.count = (int64_t)c->nodes.size();
+#ifdef REF_SPHERES
+    Spheres.data = reinterpret_cast<const Sphere*>(c->spheres.data());
+    Spheres.count = (int64_t)c->spheres.size();
+    sphereCount = (int)c->spheres.size();
+#endif
     modelCount = (int)c->models.size();       /* RCM:156 */
     triangleCount = (int)c->triangles.size(); /* RCM:157 (unused by the kernel) */
     FrameRender.data = c->frameRender.data();
@@ -115,8 +127,11 @@ void bind(RefContext* c)
 /* Dispatch(kernel, ceil(W/8), ceil(H/8), 1) with [numthreads(8,8,1)]: every thread id of the padded grid */
 template <class K> void dispatch(RefContext* c, K kernel)
 {
-    const int gw = (c->W + 7) / 8 * 8, gh = (c->H + 7) / 8 * 8;
-    std::atomic<int> nextRow(0);
+    const int gw = (c->W + 7) / 8 * 8;
+    int gh = (c->H + 7) / 8 * 8, g0 = 0;
+    if (c->rowBegin >= 0) g0 = c->rowBegin < gh ? c->rowBegin : gh;
+    if (c->rowEnd >= 0 && c->rowEnd < gh) gh = c->rowEnd > g0 ? c->rowEnd : g0;
+    std::atomic<int> nextRow(g0);
     std::mutex sum;
     auto worker = [&]() {
         g_ref_stats[0] = g_ref_stats[1] = 0;
@@ -160,6 +175,14 @@ int ref_set_threads(RefContext* c, int n)
     c->threads = n;
     return RT_OK;
 }
+/* the dispatcher's (not the reference's): thread ids of rows [row_begin, row_end) only; negative = all */
+int ref_set_row_window(RefContext* c, int row_begin, int row_end)
+{
+    if (!c) return RT_ERR_INVALID_ARG;
+    c->rowBegin = row_begin;
+    c->rowEnd = row_end;
+    return RT_OK;
+}
 int ref_resize(RefContext* c, int w, int h) /* RCM:126-133 */
 {
     if (!c || w <= 0 || h <= 0) return RT_ERR_INVALID_ARG;
@@ -173,8 +196,13 @@ int ref_upload_scene(RefContext* c, const RtModel* models, int n_models, const R
                      const RtBVHNode* nodes, int n_nodes, const RtSphere* spheres, int n_spheres)
 {
     if (!c || n_models < 0 || n_tris < 0 || n_nodes < 0) return RT_ERR_INVALID_ARG;
+#ifdef REF_SPHERES
+    if (n_spheres < 0 || (n_spheres && !spheres)) return RT_ERR_INVALID_ARG;
+    c->spheres.assign(spheres, spheres + n_spheres);
+#else
     if (n_spheres != 0) return fail(c, RT_ERR_SCENE, "the reference has no sphere buffer (RC:341 is commented out)");
     (void)spheres;
+#endif
     c->models.assign(models, models + n_models);
     c->triangles.assign(tris, tris + n_tris);
     c->nodes.assign(nodes, nodes + n_nodes);
@@ -187,7 +215,16 @@ int ref_update_models(RefContext* c, const RtModel* models, int n) /* RCM:192-20
     c->models.assign(models, models + n);
     return RT_OK;
 }
+#ifdef REF_SPHERES
+int ref_update_spheres(RefContext* c, const RtSphere* spheres, int n)
+{
+    if (!c || n != (int)c->spheres.size()) return RT_ERR_INVALID_ARG;
+    c->spheres.assign(spheres, spheres + n);
+    return RT_OK;
+}
+#else
 int ref_update_spheres(RefContext* c, const RtSphere*, int n) { return (c && n == 0) ? RT_OK : RT_ERR_SCENE; }
+#endif
 int ref_set_params(RefContext* c, const RtParams* p)
 {
     if (!c || !p) return RT_ERR_INVALID_ARG;
@@ -257,7 +294,9 @@ int ref_get_counters(RefContext* c, RtCounters* out)
     out->pixelFrames = c->pixelFrames;
     return RT_OK;
 }
-#ifndef RT_MATH_IEEE
+#ifdef REF_SPHERES
+const char* ref_version(void) { return "reference HLSL text + the declared sphere hook S1 (RC:341), compiled through oracle/ref_compat.h (test infrastructure)"; }
+#elif !defined(RT_MATH_IEEE)
 const char* ref_version(void) { return "reference HLSL text compiled through oracle/ref_compat.h (test infrastructure)"; }
 #else
 const char* ref_version(void) { return "reference HLSL text compiled through oracle/ref_compat.h (test infrastructure) RT_MATH_IEEE"; }

@@ -13,7 +13,13 @@ _spec.loader.exec_module(make_ref)
 
 
 def lib_path(variant=""):
-    return os.path.join(_HERE, "_ref", "libref_ieee.so" if variant == "ieee" else "libref.so")
+    return os.path.join(_HERE, "_ref", {"ieee": "libref_ieee.so", "spheres": "libref_spheres.so"}.get(variant, "libref.so"))
+
+
+def stale_reason(libraries=("libref.so",)):
+    """None, or why the libraries under oracle/_ref must not be trusted (make_ref.check_manifest): built from other reference
+    sources or another recipe than oracle/REF_EXPECTED.json names, or not the files MANIFEST.json describes."""
+    return make_ref.check_manifest(list(libraries))
 
 
 def build(variant="", force=False):
@@ -23,7 +29,7 @@ def build(variant="", force=False):
         deps = [os.path.join(_HERE, f) for f in ("make_ref.py", "ref_compat.h", "ref_driver.h", "../include/rt_math.h", "../include/rt_abi.h")]
         deps += [os.path.join(make_ref.SHADER_DIR, s) for s in make_ref.SOURCES]
         if force or not os.path.exists(path) or any(os.path.getmtime(d) > os.path.getmtime(path) for d in deps):
-            make_ref.build(ieee=(variant == "ieee"), quiet=True)
+            make_ref.build(ieee=(variant == "ieee"), spheres=(variant == "spheres"), quiet=True)
     return path if os.path.exists(path) else None
 
 
@@ -50,6 +56,7 @@ def load(pkg, variant=""):
             f3 = C.POINTER(C.c_float)
             self._bind("create", C.c_int, [C.POINTER(C.c_void_p)])
             self._bind("set_threads", C.c_int, [C.c_void_p, C.c_int])
+            self._bind("set_row_window", C.c_int, [C.c_void_p, C.c_int, C.c_int])
             self._bind("next_random", C.c_uint32, [C.POINTER(C.c_uint32)])
             self._bind("random_value", C.c_float, [C.POINTER(C.c_uint32)])
             self._bind("random_direction", None, [C.POINTER(C.c_uint32), f3])

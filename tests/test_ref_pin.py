@@ -6,8 +6,9 @@ HLSL leaves to its compiler) into oracle/_ref/libref.so.  These tests demand tha
 restatement every other test in this repository compares the HIP kernels with — produces the SAME BITS as that library:
 whole FrameRender / AccumulatedRender images of the BVH configs and of all five reference scenes, the shader's own
 `stats` counters (RC:254,271), every intersection / shading / RNG function on random inputs, and the same again under the
-RT_MATH_IEEE reading.  The reference has no sphere buffer (RC:341), so whole images are model-only scenes; RaySphere
-(RC:289-332, the basis of the sphere extension) is compared at function level.
+RT_MATH_IEEE reading.  The reference has no sphere buffer (RC:341), so whole images of libref.so are model-only scenes and
+RaySphere (RC:289-332) is compared at function level; the sphere extension's HOOK is pinned by libref_spheres.so = the same
+text + the one declared semantic rewrite S1 of make_ref.py, on BASELINE configs 1 and 2 (round 5).
 
 The rewrite list is checked to be syntactic: undoing each rewrite on the generated text gives back the reference's text
 token for token (test_rewrites_are_only_the_listed_syntactic_ones).
@@ -272,6 +273,143 @@ def test_spheres_are_refused_by_the_reference_text(pkg, orc, ref):
     with pytest.raises(pkg.abi.RtError):
         mgr.OnEnable(renderSeed=1)
     tr.close()
+
+
+# ------------------------------------------------------------------------------------------------ the sphere hook (S1)
+@pytest.fixture(scope="module")
+def ref_spheres(pkg):
+    lib = ref_lib.load(pkg, "spheres")
+    if lib is None:
+        pytest.skip("oracle/_ref/libref_spheres.so absent and no reference checkout to build it from")
+    return lib
+
+
+def render_pair_with_spheres(pkg, orc_lib, ref_lib_, scene_factory, w, h, frames, seed, tweak=None):
+    out = []
+    for lib in (orc_lib, ref_lib_):
+        tr = lib.create_tracer(THREADS)
+        mgr = scene_factory().make_manager(tr, orc_lib, w, h)
+        if tweak:
+            tweak(mgr)
+        mgr.OnEnable(renderSeed=seed)
+        for _ in range(frames):
+            mgr.RenderFrame()
+        out.append((tr.read_accumulated(), tr.read_frame(), tr.counters(), tr.frame()))
+        tr.close()
+    return out
+
+
+SPHERE_IMAGES = [  # BASELINE configs 1 and 2 — the headline image — and sphere + BVH mixtures
+    ("config1_exact", 1, {}, 256, 256, 1, 1, None),
+    ("config1_three_frames", 1, {}, 96, 96, 3, 5, None),
+    ("config2_headline", 2, {}, 240, 135, 2, 1, None),
+    ("config2_sky_off", 2, {}, 96, 54, 2, 3, lambda m: setattr(m, "useSky", False)),
+    ("config2_dof", 2, {}, 96, 54, 1, 9, lambda m: (setattr(m, "defocusStrength", 60.0), setattr(m, "focusDistance", 7.0))),
+]
+
+
+@pytest.mark.parametrize("case", SPHERE_IMAGES, ids=[c[0] for c in SPHERE_IMAGES])
+def test_oracle_equals_the_reference_text_with_the_sphere_hook(pkg, orc, ref_spheres, case):
+    """libref_spheres.so = the reference's text + the declared rewrite S1 (make_ref.py): the reference's own RaySphere (RC:289-332)
+    called from the place of its commented call (RC:341), the sphere's material in place of the hard-coded one.  The oracle's hook —
+    order against the model loop, strict '<' between equal hits, the material substitution — must give the same bits, on BASELINE
+    config 1 exactly and on config 2, the headline image."""
+    name, cfg, kw, w, h, frames, seed, tweak = case
+    out = render_pair_with_spheres(pkg, orc, ref_spheres, lambda: pkg.scenes.get(cfg, **kw), w, h, frames, seed, tweak)
+    assert_same(out, name)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_scenes_with_spheres_and_models(pkg, orc, ref_spheres, seed):
+    """the GPU suite's fuzz generator WITH its spheres: spheres inside / in front of / behind meshes, glass spheres, equal hits"""
+    from test_gpu_fuzz import random_scene
+    sc0, render_seed = random_scene(pkg, seed)
+    out = render_pair_with_spheres(pkg, orc, ref_spheres, lambda: random_scene(pkg, seed)[0], sc0.width, sc0.height, sc0.frames, render_seed)
+    assert_same(out, f"fuzz {seed} with spheres")
+
+
+def test_coincident_spheres_keep_the_first(pkg, orc, ref_spheres):
+    """two identical spheres with different materials: strict '<' (the hook's `sphereHit.dst < result.dst`) keeps buffer order"""
+    def factory():
+        sc = pkg.scenes.get(1)
+        import copy
+        twin = copy.deepcopy(sc.spheres[0])
+        twin.material.diffuseCol = (0.1, 0.9, 0.1, 1)
+        sc.spheres.insert(1, twin)
+        return sc
+    out = render_pair_with_spheres(pkg, orc, ref_spheres, factory, 64, 64, 1, 1)
+    assert_same(out, "coincident spheres")
+
+
+def test_row_window_of_the_dispatcher(pkg, orc, ref_spheres):
+    """ref_set_row_window (the dispatcher's, used by bench.py's in-run check at 1920x1080): strips of the reference text == the same
+    strips of the oracle == those rows of the whole image"""
+    W, H, strips = 96, 54, (0, 3, 6)
+    imgs = []
+    for lib in (orc, ref_spheres):
+        whole = lib.create_tracer(THREADS)
+        m = pkg.scenes.get(2).make_manager(whole, orc, W, H)
+        m.OnEnable(renderSeed=1)
+        m.RenderFrame()
+        part = lib.create_tracer(THREADS)
+        m2 = pkg.scenes.get(2).make_manager(part, orc, W, H)
+        m2.OnEnable(renderSeed=1)
+        for s_ in strips:
+            m2.numAccumulatedFrames = 1
+            m2.SetShaderParams()
+            lib.set_row_window(part.h, s_ * 8, min(H, s_ * 8 + 8))
+            part.render_frame()
+        rows = np.concatenate([np.arange(s_ * 8, min(H, s_ * 8 + 8)) for s_ in strips])
+        a, b = whole.read_accumulated(), part.read_accumulated()
+        assert np.array_equal(bits(a[rows]), bits(b[rows]))
+        other = np.setdiff1d(np.arange(H), rows)
+        assert not b[other].any()
+        imgs.append(b[rows])
+        whole.close(), part.close()
+    assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
+
+
+@pytest.mark.skipif(not ref_lib.make_ref.available(), reason="needs the reference checkout")
+def test_the_sphere_hook_is_the_only_semantic_rewrite():
+    """Take S1's two insertions out of the --spheres translation unit: what is left is the plain translation unit, character for
+    character — libref_spheres.so differs from libref.so by the declared hook and nothing else."""
+    mk = ref_lib.make_ref
+    plain, hooked = mk.translation_unit(), mk.translation_unit(spheres=True)
+    assert plain != hooked
+    with open(os.path.join(mk.SHADER_DIR, "RayCommon.hlsl"), encoding="utf-8-sig") as f:
+        original = f.read().replace("\r\n", "\n")
+    decl, hook, call = mk.rewrite(mk.S1_DECL), mk.rewrite(mk.S1_HOOK), mk.rewrite(mk.S1_COMMENTED_CALL)
+    assert hooked.count(decl) == 1 and hooked.count(hook) == 1
+    assert hooked.replace(decl, "").replace(hook, call) == plain
+    # and the hook calls the reference's RaySphere, whose text is untouched (RC:289-332)
+    a = original.index("ModelHitInfo RaySphere(")
+    b = original.index("ModelHitInfo CalculateRayCollision(")
+    assert mk.rewrite(original[a:b]) in hooked
+    assert "RaySphere(worldRay.pos, worldRay.dir, sphere.centre, sphere.radius)" in hook
+
+
+# ------------------------------------------------------------------------------------------------ stale libraries
+def test_prebuilt_reference_libraries_match_the_committed_hashes():
+    """oracle/_ref travels prebuilt to the GPU box, which cannot rebuild it: MANIFEST.json (written by every build) must name the
+    inputs oracle/REF_EXPECTED.json names, the recipe files of this tree, and the libraries as they lie there."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref.so")):
+        pytest.skip("no prebuilt oracle/_ref")
+    why = ref_lib.stale_reason(["libref.so", "libref_ieee.so", "libref_spheres.so", "libref_bvh.so"])
+    assert why is None, why
+
+
+@pytest.mark.skipif(not ref_lib.make_ref.available(), reason="needs the reference checkout")
+def test_editing_the_recipe_without_rebuilding_is_noticed(tmp_path, monkeypatch):
+    """the check reads the recipe files of the tree it runs in: a changed header with an unchanged library is stale"""
+    mk = ref_lib.make_ref
+    assert mk.check_manifest(["libref.so"]) is None
+    real = mk._sha
+    monkeypatch.setattr(mk, "_sha", lambda path: "0" * 64 if path.endswith("ref_compat.h") else real(path))
+    why = mk.check_manifest(["libref.so"])
+    assert why and "ref_compat.h" in why
+    monkeypatch.setattr(mk, "_sha", lambda path: "0" * 64 if path.endswith("libref.so") else real(path))
+    why = mk.check_manifest(["libref.so"])
+    assert why and "libref.so" in why
 
 
 # ------------------------------------------------------------------------------------------------ the recipe
