@@ -68,6 +68,10 @@ struct Counters {
  *   'K' miss (sky) | 'O' opaque hit | 'G' glass hit | 'E' path ended */
 static thread_local std::vector<uint8_t>* g_schedTrace = nullptr;
 static inline void sched_tok(uint8_t t) { if (g_schedTrace) g_schedTrace->push_back(t); }
+/* ... and of the NODES it visits, for tools/layout_sim.py (which device-memory layout touches how many cache lines):
+ *   0xFFFFFFFF segment start | i = inner step, i = absolute index of the popped node's FIRST child | 0x80000000 | i = leaf, i = its node index */
+static thread_local std::vector<uint32_t>* g_nodeTrace = nullptr;
+static inline void node_tok(uint32_t t) { if (g_nodeTrace) g_nodeTrace->push_back(t); }
 
 struct Ray { /* RC:35-47 */
     float3 pos, dir, invDir, transmittance;
@@ -200,12 +204,14 @@ static TriangleHitInfo RayTriangleBVH(const Scene& sc, const Ray& ray, float ray
     stack[stackCount++] = nodeOffset + 0;
 
     while (stackCount > 0) {
-        const RtBVHNode& node = sc.nodes[stack[--stackCount]];
+        const int nodeIndex = stack[--stackCount];
+        const RtBVHNode& node = sc.nodes[nodeIndex];
         bool isLeaf = node.triangleCount > 0;
 
         if (isLeaf) {
             stats.leafSteps++;
             sched_tok('C'); sched_tok((uint8_t)(node.triangleCount > 255 ? 255 : node.triangleCount)); sched_tok((uint8_t)stackCount);
+            node_tok(0x80000000u | (uint32_t)nodeIndex);
             for (int i = 0; i < node.triangleCount; i++) {
                 const RtTriangle& tri = sc.triangles[triOffset + node.startIndex + i];
                 TriangleHitInfo triHitInfo = RayTriangle(ray, tri, cullBackface);
@@ -218,6 +224,7 @@ static TriangleHitInfo RayTriangleBVH(const Scene& sc, const Ray& ray, float ray
         } else {
             stats.innerSteps++;
             sched_tok('B'); sched_tok((uint8_t)stackCount);
+            node_tok((uint32_t)(nodeOffset + node.startIndex));
             int childIndexA = nodeOffset + node.startIndex + 0;
             int childIndexB = nodeOffset + node.startIndex + 1;
             const RtBVHNode& childA = sc.nodes[childIndexA];
@@ -282,6 +289,7 @@ static ModelHitInfo CalculateRayCollision(const Scene& sc, const Ray& worldRay, 
     result.dst = RT_INF;
     stats.segments++;
     sched_tok('S');
+    node_tok(0xFFFFFFFFu);
 
     /* Extension S1, hooked at the commented-out call RC:341: analytic spheres are
      * tested first, in buffer order, strict '<' keeps the first of equal hits. */
@@ -1098,6 +1106,18 @@ int oracle_trace_pixel_schedule(OracleContext* ctx, int x, int y, int frame, uin
     g_schedTrace = nullptr;
     int n = (int)log.size();
     if (buf) memcpy(buf, log.data(), (size_t)(n < cap ? n : cap));
+    return n;
+}
+/* oracle_trace_pixel with the node log switched on; returns the log's length in entries (copied: min(len, cap)). */
+int oracle_trace_pixel_nodes(OracleContext* ctx, int x, int y, int frame, uint32_t* buf, int cap)
+{
+    std::vector<uint32_t> log;
+    g_nodeTrace = &log;
+    float out[3];
+    oracle_trace_pixel(ctx, x, y, frame, out);
+    g_nodeTrace = nullptr;
+    int n = (int)log.size();
+    if (buf) memcpy(buf, log.data(), (size_t)(n < cap ? n : cap) * 4);
     return n;
 }
 /* rt_math.h primitives over arrays. op: 0 log 1 exp 2 sin 3 cos 4 sqrt 5 pow(x,y) 6 div(x/y) 7 smoothstep(0,y,x) */

@@ -13,7 +13,7 @@
  * RT_LAYOUT (comma separated; default = the layout measured best, profiles/r05_ab_layout.txt):
  *     dense     pairs in post-order, triangles in the caller's order, no padding (rounds 1-4)
  *     pre       pairs in pre-order (a pair is followed by its FIRST child's subtree)
- *     hot=K     the top K levels of every tree breadth-first in one block ahead of everything else
+ *     hot=K     the top K levels of every tree breadth-first in one block at the front of the tree's region
  *     align     a leaf's run never crosses a 128-byte line it need not cross (padding)
  *     arena     ONE space for pairs and triangles: a pair is followed by the runs of its leaf children
  *     palign    (arena) a pair never straddles a 128-byte line
@@ -28,7 +28,10 @@
 #include <string.h>
 #include <sys/mman.h>
 
+#include <algorithm>
+#include <atomic>
 #include <map>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -260,22 +263,147 @@ struct LayoutEngine {
         return true;
     }
 
-    /* ---- everything else: a walk per mesh instance decides the places */
-    struct Placed { uint32_t pair; int side; uint32_t unit; uint32_t start, count; }; /* pair = UINT32_MAX: the instance's leaf root */
+    /* ---- everything else: a walk per mesh instance decides the places.  Every instance is laid out on its own (relative units, in
+     * parallel), a prefix sum over the instances' sizes gives the bases: [instance 0: hot block | the rest][instance 1: ...] ... */
+    struct Placed { uint32_t pair; int side; uint32_t unit; uint32_t start, count; }; /* pair = UINT32_MAX: the instance's leaf root; unit relative to the instance's triangle region */
     struct Inst {
         uint32_t root;
         int triOffset;
         std::vector<int> modelsOf;
         std::vector<Placed> leaves;
-        uint32_t triBase = 0;
+        std::vector<std::pair<uint32_t, uint32_t>> pairs; /* (canonical pair, unit relative to the instance's pair region) */
+        uint64_t pairUnits = 0, triUnits = 0;             /* region sizes (arena: pairUnits only) */
+        uint64_t pairBase = 0, triBase = 0;               /* absolute first unit of the regions */
+        uint64_t placedTris = 0;
+        uint32_t triBaseCode = 0;                         /* what the leaf codes are relative to */
+        bool irregular = false;
     };
+
+    /* one instance, relative placement; owner[] = the instance that claimed a pair (a second claim = not a forest of meshes) */
+    void lay_instance(const RtLayout& L, Inst& I, int k, std::atomic<int32_t>* owner)
+    {
+        const bool arena = L.triMode == 2;
+        uint64_t pairCur = 0, triCur = 0;
+        auto claim = [&](uint32_t p) {
+            int32_t expect = -1;
+            if (!owner[p].compare_exchange_strong(expect, (int32_t)k)) I.irregular = true;
+        };
+        auto place_pair = [&](uint32_t p) {
+            if (L.pairAlign && (pairCur % RT_LINE_UNITS) > RT_LINE_UNITS - RT_PAIR_UNITS) pairCur = (pairCur / RT_LINE_UNITS + 1) * RT_LINE_UNITS;
+            I.pairs.push_back({p, (uint32_t)pairCur});
+            pairCur += RT_PAIR_UNITS;
+        };
+        auto place_run = [&](uint32_t pair, int side, uint32_t start, uint32_t count) {
+            uint64_t& cur = arena ? pairCur : triCur;
+            const uint64_t n = (uint64_t)count * RT_TRI_UNITS;
+            if (L.triMode == 1) { /* a line crossing that padding can remove is removed */
+                const uint64_t lines = (cur % RT_LINE_UNITS + n + RT_LINE_UNITS - 1) / RT_LINE_UNITS, least = (n + RT_LINE_UNITS - 1) / RT_LINE_UNITS;
+                if (lines > least) cur = (cur / RT_LINE_UNITS + 1) * RT_LINE_UNITS;
+            }
+            I.leaves.push_back({pair, side, (uint32_t)cur, start, count});
+            cur += n;
+            I.placedTris += count;
+        };
+        auto leaf_children = [&](uint32_t p) {
+            const uint32_t codes[2] = {canon[p].codeA, canon[p].codeB};
+            for (int s = 0; s < 2; s++)
+                if (codes[s] & RT_CODE_LEAF) {
+                    uint32_t start, count;
+                    decode_leaf(codes[s], &start, &count);
+                    place_run(p, s, start, count);
+                }
+        };
+        if (I.root & RT_CODE_LEAF) {
+            uint32_t start, count;
+            decode_leaf(I.root, &start, &count);
+            place_run(UINT32_MAX, 0, start, count);
+        } else {
+            claim(I.root);
+            /* 1. the hot block: the top levels breadth-first (hot pairs are marked by unit != UINT32_MAX in `hotUnit`) */
+            std::vector<uint32_t> hotList;
+            if (L.hotLevels) {
+                std::vector<uint32_t> level(1, I.root), next;
+                for (int d = 0; d < L.hotLevels && !level.empty() && !I.irregular; d++) {
+                    next.clear();
+                    for (uint32_t p : level) {
+                        hotList.push_back(p);
+                        place_pair(p);
+                        const uint32_t codes[2] = {canon[p].codeA, canon[p].codeB};
+                        for (int s = 0; s < 2; s++)
+                            if (!(codes[s] & RT_CODE_LEAF)) { claim(codes[s]); next.push_back(codes[s]); }
+                    }
+                    level.swap(next);
+                }
+                if (arena) /* leaves hanging off the hot pairs: behind the block */
+                    for (uint32_t p : hotList) leaf_children(p);
+            }
+            std::sort(hotList.begin(), hotList.end());
+            auto is_hot = [&](uint32_t p) { return !hotList.empty() && std::binary_search(hotList.begin(), hotList.end(), p); };
+            /* 2. the rest, depth-first; a child the hot pass already claimed (hot itself, or the frontier below it) is ours */
+            const size_t nHot = hotList.size();
+            std::vector<uint32_t> frontier; /* claimed by the hot pass, not hot: the level below the block */
+            if (nHot) {
+                for (uint32_t p : hotList) {
+                    const uint32_t codes[2] = {canon[p].codeA, canon[p].codeB};
+                    for (int s = 0; s < 2; s++)
+                        if (!(codes[s] & RT_CODE_LEAF) && !is_hot(codes[s])) frontier.push_back(codes[s]);
+                }
+                std::sort(frontier.begin(), frontier.end());
+            }
+            auto preclaimed = [&](uint32_t p) { return nHot && (is_hot(p) || std::binary_search(frontier.begin(), frontier.end(), p)); };
+            struct Frame { uint32_t p; int stage; bool hot; };
+            std::vector<Frame> stack;
+            stack.push_back({I.root, 0, is_hot(I.root)});
+            while (!stack.empty() && !I.irregular) {
+                Frame& f = stack.back();
+                const uint32_t p = f.p;
+                if (f.stage == 0) {
+                    if (L.preorder) {
+                        if (!f.hot) {
+                            place_pair(p);
+                            if (arena) leaf_children(p);
+                        }
+                        if (!arena) leaf_children(p);
+                    }
+                    f.stage = 1;
+                    const uint32_t c = canon[p].codeA;
+                    if (!(c & RT_CODE_LEAF)) {
+                        if (!preclaimed(c)) claim(c);
+                        const bool h = is_hot(c);
+                        stack.push_back({c, 0, h});
+                    }
+                    continue;
+                }
+                if (f.stage == 1) {
+                    f.stage = 2;
+                    const uint32_t c = canon[p].codeB;
+                    if (!(c & RT_CODE_LEAF)) {
+                        if (!preclaimed(c)) claim(c);
+                        const bool h = is_hot(c);
+                        stack.push_back({c, 0, h});
+                    }
+                    continue;
+                }
+                if (!L.preorder) {
+                    if (!f.hot) {
+                        place_pair(p);
+                        if (arena) leaf_children(p);
+                    }
+                    if (!arena) leaf_children(p);
+                }
+                stack.pop_back();
+                if ((int)stack.size() > RT_MAX_BVH_DEPTH + 2) I.irregular = true; /* (convert() bounds the height; a shared pair below the hot block could loop) */
+            }
+        }
+        I.pairUnits = pairCur;
+        I.triUnits = triCur;
+    }
 
     bool run(const RtLayout& L, PodVec<DPair>& canonStore, LaidOutScene& out)
     {
         if (L.dense()) return run_dense(canonStore, out);
         /* instances = distinct (root, triOffset), in the order the models name them */
         std::vector<Inst> insts;
-        std::vector<int> instOfModel(nModels, 0);
         {
             std::map<std::pair<uint32_t, int>, int> seen;
             for (int m = 0; m < nModels; m++) {
@@ -288,204 +416,122 @@ struct LayoutEngine {
                     insts.back().triOffset = models[m].triOffset;
                 }
                 insts[it->second].modelsOf.push_back(m);
-                instOfModel[m] = it->second;
             }
         }
         const bool arena = L.triMode == 2;
-        std::vector<int32_t> owner(nCanon, -1);   /* instance that placed / will place the pair */
-        std::vector<uint32_t> unitOf(nCanon, UINT32_MAX);
-        uint64_t pairCur = 0, triCur = 0;         /* next free unit of the two spaces (arena: pairCur only) */
-        uint64_t placedTris = 0;
+        std::unique_ptr<std::atomic<int32_t>[]> owner(new std::atomic<int32_t>[nCanon ? nCanon : 1]);
+        par((int)((nCanon + (1 << 16) - 1) >> 16), [&](int b) {
+            const size_t i1 = ((size_t)b + 1) << 16 < nCanon ? ((size_t)b + 1) << 16 : nCanon;
+            for (size_t i = (size_t)b << 16; i < i1; i++) owner[i].store(-1, std::memory_order_relaxed);
+        });
+        par((int)insts.size(), [&](int k) { lay_instance(L, insts[k], k, owner.get()); });
         bool irregular = false;
-
-        auto place_pair = [&](uint32_t p) {
-            if (L.pairAlign && (pairCur % RT_LINE_UNITS) > RT_LINE_UNITS - RT_PAIR_UNITS) pairCur = (pairCur / RT_LINE_UNITS + 1) * RT_LINE_UNITS;
-            unitOf[p] = (uint32_t)pairCur;
-            pairCur += RT_PAIR_UNITS;
-        };
-        auto place_run = [&](Inst& I, uint32_t pair, int side, uint32_t start, uint32_t count) {
-            uint64_t& cur = arena ? pairCur : triCur;
-            const uint64_t n = (uint64_t)count * RT_TRI_UNITS;
-            if (L.triMode == 1) { /* a line crossing that padding can remove is removed */
-                const uint64_t lines = (cur % RT_LINE_UNITS + n + RT_LINE_UNITS - 1) / RT_LINE_UNITS, least = (n + RT_LINE_UNITS - 1) / RT_LINE_UNITS;
-                if (lines > least) cur = (cur / RT_LINE_UNITS + 1) * RT_LINE_UNITS;
-            }
-            I.leaves.push_back({pair, side, (uint32_t)cur, start, count});
-            cur += n;
-            placedTris += count;
-        };
-        auto leaf_children = [&](Inst& I, uint32_t p) {
-            const uint32_t codes[2] = {canon[p].codeA, canon[p].codeB};
-            for (int s = 0; s < 2; s++)
-                if (codes[s] & RT_CODE_LEAF) {
-                    uint32_t start, count;
-                    decode_leaf(codes[s], &start, &count);
-                    place_run(I, p, s, start, count);
-                }
-        };
-
-        /* 1. the hot block: the top levels of every tree, breadth-first, tree after tree */
-        std::vector<char> hot(nCanon, 0);
-        for (size_t k = 0; k < insts.size() && !irregular; k++) {
-            Inst& I = insts[k];
-            if (I.root & RT_CODE_LEAF) continue;
-            if (owner[I.root] >= 0) { irregular = true; break; } /* two instances over the same pairs (same nodes, other triangles) */
-            owner[I.root] = (int32_t)k;
-            if (!L.hotLevels) continue;
-            std::vector<uint32_t> level(1, I.root), next;
-            for (int d = 0; d < L.hotLevels && !level.empty(); d++) {
-                next.clear();
-                for (uint32_t p : level) {
-                    hot[p] = 1;
-                    place_pair(p);
-                    const uint32_t codes[2] = {canon[p].codeA, canon[p].codeB};
-                    for (int s = 0; s < 2; s++)
-                        if (!(codes[s] & RT_CODE_LEAF)) {
-                            if (owner[codes[s]] >= 0) { irregular = true; break; }
-                            owner[codes[s]] = (int32_t)k;
-                            next.push_back(codes[s]);
-                        }
-                    if (irregular) break;
-                }
-                level.swap(next);
-                if (irregular) break;
-            }
+        uint64_t pairCur = 0, triCur = 0, placedTris = 0;
+        for (Inst& I : insts) {
+            irregular = irregular || I.irregular;
+            /* an instance starts on a line (its own padding rules are relative to its start) */
+            pairCur = (pairCur + RT_LINE_UNITS - 1) / RT_LINE_UNITS * RT_LINE_UNITS;
+            triCur = (triCur + RT_LINE_UNITS - 1) / RT_LINE_UNITS * RT_LINE_UNITS;
+            I.pairBase = pairCur;
+            I.triBase = arena ? pairCur : triCur;
+            pairCur += I.pairUnits;
+            triCur += I.triUnits;
+            placedTris += I.placedTris;
         }
-        if (L.hotLevels && arena && !irregular) /* leaves hanging off the hot pairs: behind the block */
-            for (size_t k = 0; k < insts.size(); k++) {
-                Inst& I = insts[k];
-                if (I.root & RT_CODE_LEAF) continue;
-                std::vector<uint32_t> level(1, I.root), next;
-                while (!level.empty()) {
-                    next.clear();
-                    for (uint32_t p : level) {
-                        if (!hot[p]) continue;
-                        leaf_children(I, p);
-                        if (!(canon[p].codeA & RT_CODE_LEAF)) next.push_back(canon[p].codeA);
-                        if (!(canon[p].codeB & RT_CODE_LEAF)) next.push_back(canon[p].codeB);
-                    }
-                    level.swap(next);
-                }
-            }
-
-        /* 2. the rest, depth-first, instance after instance */
-        struct Frame { uint32_t p; int stage; };
-        std::vector<Frame> stack;
-        std::vector<char> walked(nCanon, 0); /* a pair reached twice (a node graph that is not a forest) is irregular */
-        for (size_t k = 0; k < insts.size() && !irregular; k++) {
-            Inst& I = insts[k];
-            if (I.root & RT_CODE_LEAF) {
-                uint32_t start, count;
-                decode_leaf(I.root, &start, &count);
-                place_run(I, UINT32_MAX, 0, start, count);
-                continue;
-            }
-            stack.clear();
-            stack.push_back({I.root, 0});
-            walked[I.root] = 1;
-            while (!stack.empty() && !irregular) {
-                Frame& f = stack.back();
-                const uint32_t p = f.p;
-                if (f.stage == 0) {
-                    if (!hot[p] && L.preorder) {
-                        place_pair(p);
-                        if (arena) leaf_children(I, p);
-                    }
-                    if (!arena && L.preorder) leaf_children(I, p);
-                    f.stage = 1;
-                    const uint32_t c = canon[p].codeA;
-                    if (!(c & RT_CODE_LEAF)) {
-                        if (walked[c] || (owner[c] >= 0 && owner[c] != (int32_t)k)) { irregular = true; break; }
-                        owner[c] = (int32_t)k;
-                        walked[c] = 1;
-                        stack.push_back({c, 0});
-                    }
-                    continue;
-                }
-                if (f.stage == 1) {
-                    f.stage = 2;
-                    const uint32_t c = canon[p].codeB;
-                    if (!(c & RT_CODE_LEAF)) {
-                        if (walked[c] || (owner[c] >= 0 && owner[c] != (int32_t)k)) { irregular = true; break; }
-                        owner[c] = (int32_t)k;
-                        walked[c] = 1;
-                        stack.push_back({c, 0});
-                    }
-                    continue;
-                }
-                if (!L.preorder) {
-                    if (!hot[p]) {
-                        place_pair(p);
-                        if (arena) leaf_children(I, p);
-                    }
-                    if (!arena) leaf_children(I, p);
-                }
-                stack.pop_back();
-            }
-            if (placedTris > 2ull * (uint64_t)nTris + 1024) irregular = true; /* leaves that overlap each other en masse */
-        }
-        if (placedTris > 2ull * (uint64_t)nTris + 1024) irregular = true;
+        if (placedTris > 2ull * (uint64_t)nTris + 1024) irregular = true; /* leaves that overlap each other en masse */
         if (irregular || pairCur * RT_UNIT_BYTES >= ((uint64_t)1 << 32) || triCur * RT_UNIT_BYTES >= ((uint64_t)1 << 32)) {
-            RtLayout d;
             const bool ok = run_dense(canonStore, out);
-            out.used = d;
+            out.used = RtLayout();
             return ok;
         }
 
-        /* 3. final codes (sequential: the table of oversized leaves is deterministic) */
+        /* final codes: the inline ones in parallel, the oversized leaves afterwards in instance order (a deterministic table) */
         out.arena = arena;
         out.used = L;
         out.rootCodes.assign(nModels, 0u);
         out.triBase.assign(nModels, 0);
-        std::vector<uint32_t> leafCode(2 * nCanon, 0u);
-        for (Inst& I : insts) {
+        std::vector<uint32_t> unitOf(nCanon, UINT32_MAX), leafCode(2 * nCanon, 0u);
+        std::vector<uint32_t> rootCode(insts.size(), 0u);
+        std::vector<std::vector<size_t>> later(insts.size());
+        par((int)insts.size(), [&](int k) {
+            Inst& I = insts[k];
+            for (const auto& pu : I.pairs) unitOf[pu.first] = (uint32_t)(I.pairBase + pu.second);
             uint32_t lo = UINT32_MAX;
             for (const Placed& q : I.leaves) lo = q.unit < lo ? q.unit : lo;
-            I.triBase = I.leaves.empty() ? 0u : lo;
-            uint32_t rootCode = (I.root & RT_CODE_LEAF) ? 0u : unitOf[I.root];
-            for (const Placed& q : I.leaves) {
+            I.triBaseCode = I.leaves.empty() ? 0u : (uint32_t)(I.triBase + lo);
+            for (size_t n = 0; n < I.leaves.size(); n++) {
+                const Placed& q = I.leaves[n];
+                const uint32_t rel = (uint32_t)(I.triBase + q.unit) - I.triBaseCode;
+                if (q.count <= RT_CODE_MAX_INLINE_COUNT && rel <= RT_CODE_MAX_INLINE_START) {
+                    const uint32_t code = RT_CODE_LEAF | (q.count << 24) | rel;
+                    if (q.pair == UINT32_MAX) rootCode[k] = code;
+                    else leafCode[2 * (size_t)q.pair + q.side] = code;
+                } else {
+                    later[k].push_back(n);
+                }
+            }
+        });
+        for (size_t k = 0; k < insts.size(); k++) {
+            Inst& I = insts[k];
+            for (size_t n : later[k]) {
+                const Placed& q = I.leaves[n];
                 uint32_t code;
-                if (!encode_leaf(q.unit - I.triBase, q.count, out.bigLeaves, &code)) { out.error = "too many oversized leaves"; return false; }
-                if (q.pair == UINT32_MAX) rootCode = code;
+                if (!encode_leaf((uint32_t)(I.triBase + q.unit) - I.triBaseCode, q.count, out.bigLeaves, &code)) { out.error = "too many oversized leaves"; return false; }
+                if (q.pair == UINT32_MAX) rootCode[k] = code;
                 else leafCode[2 * (size_t)q.pair + q.side] = code;
             }
+            if (!(I.root & RT_CODE_LEAF)) rootCode[k] = unitOf[I.root];
             for (int m : I.modelsOf) {
-                out.rootCodes[m] = rootCode;
-                out.triBase[m] = (int32_t)I.triBase;
+                out.rootCodes[m] = rootCode[k];
+                out.triBase[m] = (int32_t)I.triBaseCode;
             }
         }
 
-        /* 4. the buffers */
+        /* the buffers: zeroed (padding, the normals' holes under pair records) and filled in parallel */
         const size_t pairBytes = (size_t)pairCur * RT_UNIT_BYTES, triBytes = (size_t)triCur * RT_UNIT_BYTES;
         const size_t normBytes = (size_t)(arena ? pairCur : triCur) * RT_NORM_BYTES_PER_UNIT;
         if (!out.pairBuf.resize_uninit(pairBytes ? pairBytes : 64) || !out.triBuf.resize_uninit(arena ? 0 : (triBytes ? triBytes : 48)) ||
             !out.normBuf.resize_uninit(normBytes ? normBytes : 36)) { out.error = "out of host memory"; return false; }
-        memset(out.pairBuf.data(), 0, out.pairBuf.size());
-        if (!arena) memset(out.triBuf.data(), 0, out.triBuf.size());
-        memset(out.normBuf.data(), 0, out.normBuf.size());
-        const int block = 1 << 14;
-        par((int)((nCanon + block - 1) / block), [&](int b) {
-            const size_t i1 = (size_t)(b + 1) * block < nCanon ? (size_t)(b + 1) * block : nCanon;
-            for (size_t i = (size_t)b * block; i < i1; i++) {
-                if (unitOf[i] == UINT32_MAX) continue; /* not reachable from any model */
-                DPair d = canon[i];
-                d.codeA = (d.codeA & RT_CODE_LEAF) ? leafCode[2 * i] : unitOf[d.codeA];
-                d.codeB = (d.codeB & RT_CODE_LEAF) ? leafCode[2 * i + 1] : unitOf[d.codeB];
-                memcpy(out.pairBuf.data() + (size_t)unitOf[i] * RT_UNIT_BYTES, &d, sizeof(d));
-            }
-        });
+        auto par_zero = [&](unsigned char* p, size_t n) {
+            const size_t blk = (size_t)4 << 20;
+            par((int)((n + blk - 1) / blk), [&](int b) { memset(p + (size_t)b * blk, 0, (size_t)(b + 1) * blk < n ? blk : n - (size_t)b * blk); });
+        };
+        par_zero(out.pairBuf.data(), out.pairBuf.size());
+        if (!arena) par_zero(out.triBuf.data(), out.triBuf.size());
+        par_zero(out.normBuf.data(), out.normBuf.size());
         unsigned char* const triSpace = arena ? out.pairBuf.data() : out.triBuf.data();
-        par((int)insts.size(), [&](int k) {
-            const Inst& I = insts[k];
-            for (const Placed& q : I.leaves)
-                for (uint32_t t = 0; t < q.count; t++) {
-                    const size_t unit = (size_t)q.unit + (size_t)t * RT_TRI_UNITS;
-                    DTri d;
-                    float n9[9];
-                    make_dtri(tris[(size_t)I.triOffset + q.start + t], d, n9);
-                    memcpy(triSpace + unit * RT_UNIT_BYTES, &d, sizeof(d));
-                    memcpy(out.normBuf.data() + unit * RT_NORM_BYTES_PER_UNIT, n9, sizeof(n9));
+        /* work items: (instance, block of its pairs) and (instance, block of its leaves) */
+        struct Item { int k; bool leaves; size_t a, b; };
+        std::vector<Item> items;
+        const size_t blk = 1 << 13;
+        for (size_t k = 0; k < insts.size(); k++) {
+            for (size_t a = 0; a < insts[k].pairs.size(); a += blk) items.push_back({(int)k, false, a, std::min(a + blk, insts[k].pairs.size())});
+            for (size_t a = 0; a < insts[k].leaves.size(); a += blk) items.push_back({(int)k, true, a, std::min(a + blk, insts[k].leaves.size())});
+        }
+        par((int)items.size(), [&](int n) {
+            const Item& it = items[n];
+            const Inst& I = insts[it.k];
+            if (!it.leaves) {
+                for (size_t a = it.a; a < it.b; a++) {
+                    const uint32_t i = I.pairs[a].first;
+                    DPair d = canon[i];
+                    d.codeA = (d.codeA & RT_CODE_LEAF) ? leafCode[2 * (size_t)i] : unitOf[d.codeA];
+                    d.codeB = (d.codeB & RT_CODE_LEAF) ? leafCode[2 * (size_t)i + 1] : unitOf[d.codeB];
+                    memcpy(out.pairBuf.data() + (size_t)unitOf[i] * RT_UNIT_BYTES, &d, sizeof(d));
                 }
+            } else {
+                for (size_t a = it.a; a < it.b; a++) {
+                    const Placed& q = I.leaves[a];
+                    for (uint32_t t = 0; t < q.count; t++) {
+                        const size_t unit = (size_t)(I.triBase + q.unit) + (size_t)t * RT_TRI_UNITS;
+                        DTri d;
+                        float n9[9];
+                        make_dtri(tris[(size_t)I.triOffset + q.start + t], d, n9);
+                        memcpy(triSpace + unit * RT_UNIT_BYTES, &d, sizeof(d));
+                        memcpy(out.normBuf.data() + unit * RT_NORM_BYTES_PER_UNIT, n9, sizeof(n9));
+                    }
+                }
+            }
         });
         canonStore.resize_uninit(0);
         return true;

@@ -115,6 +115,20 @@ def test_layout_visits_the_callers_tree(env, cfg, layout):
         assert total <= 64 * max(1, n_pairs) * 2 + 48 * len(tris) * 2 + 256
 
 
+@pytest.mark.parametrize("layout", ["dense", "pre,arena", "hot=5,align"])
+def test_layout_of_a_forest_prepared_in_parallel(env, layout):
+    """config 5's class: twelve meshes, > 2^16 nodes — the path where every mesh is converted and laid out by its own worker"""
+    pkg, api = env
+    models, tris, nodes = scene_arrays(pkg, api, (5, dict(subdivisions=4)))
+    assert len(nodes) >= 1 << 16
+    lay = api.layout_arrays(models, tris, nodes, layout)
+    assert lay["used"] == layout
+    n_pairs, n_tris = walk_and_check(models, tris, nodes, lay)
+    assert n_tris >= len(tris) - 64
+    again = api.layout_arrays(models, tris, nodes, layout)   # deterministic whatever the worker threads did
+    assert all(np.array_equal(lay[k], again[k]) for k in ("pair_space", "norm_space", "root_codes", "tri_base", "big_leaves"))
+
+
 def _walk_units(lay):
     """(pair units, [(absolute first unit, count) of every leaf run]) reachable from the root codes."""
     pair_space, big = lay["pair_space"], lay["big_leaves"]

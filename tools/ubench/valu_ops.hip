@@ -1,12 +1,17 @@
 // Issue cost of single VALU instructions on gfx950, pinned with inline asm (8 independent dependent-chains per lane,
-// 8 waves per SIMD resident): cycles per wave64 instruction per SIMD at the clock measured by wall_clock64 / events.
+// 8 waves per SIMD resident).  Round 5: every kernel runs >= 20 ms (the iteration count is a run-time argument,
+// calibrated per instruction) and measures its own clock: wave 0 reads s_memtime (shader clock) and s_memrealtime (constant 100 MHz)
+// at both ends, so "cycles per wave64 instruction per SIMD" is at the clock the instruction really ran at — round 3 assumed 2.4 GHz
+// on 0.3-ms kernels, launch ramp and clock state included.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-#define N_ITER 4096
+#define N_ITER 4096 /* calibration launch; the measured launch is scaled to >= 20 ms */
 #define REP8(OP) OP(a0) OP(a1) OP(a2) OP(a3) OP(a4) OP(a5) OP(a6) OP(a7)
 #define K(NAME, ASM)                                                                                                   \
-    __global__ void __launch_bounds__(256) k_##NAME(float* out, float seed)                                            \
+    __global__ void __launch_bounds__(256) k_##NAME(float* out, float seed, int iters, unsigned long long* clocks)     \
     {                                                                                                                  \
+        unsigned long long t0 = 0, r0 = 0;                                                                             \
+        if (blockIdx.x == 0 && threadIdx.x == 0) { t0 = __builtin_readcyclecounter(); r0 = wall_clock64(); }          \
         float a0 = seed + threadIdx.x, a1 = a0 * 1.1f, a2 = a0 * 1.2f, a3 = a0 * 1.3f, a4 = a0 * 1.4f, a5 = a0 * 1.5f, a6 = a0 * 1.6f, a7 = a0 * 1.7f; \
         float c = seed * 0.999f, d = seed * 1.001f;                                                                    \
         typedef float f2 __attribute__((ext_vector_type(2)));                                                          \
@@ -15,9 +20,10 @@
         asm volatile("s_mov_b32 s20, 0x3f7fbe77\n s_mov_b32 s21, 0x3f800347" ::: "s20", "s21");                                                                    \
         unsigned long long msk = __ballot(a0 < c);                                                                   \
         asm volatile("v_cmp_lt_f32 vcc, %0, %1" ::"v"(a0), "v"(c) : "vcc");                                           \
-        for (int i = 0; i < N_ITER; i++) {                                                                             \
+        for (int i = 0; i < iters; i++) {                                                                              \
             _Pragma("unroll") for (int u = 0; u < 1; u++) { REP8(ASM) }                                                \
         }                                                                                                              \
+        if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = __builtin_readcyclecounter() - t0; clocks[1] = wall_clock64() - r0; } \
         out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + c + d + pa0.x + pa1.y + pa2.x + pa3.y + pa4.x + pa5.y + pa6.x + pa7.y + (float)(qa0 + qa1 + qa2 + qa3 + qa4 + qa5 + qa6 + qa7);                   \
     }
 #define OP_MUL(x) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(c));
@@ -74,20 +80,27 @@ K(mullit, OP_MULLIT) K(addlit, OP_ADDLIT) K(fmalit, OP_FMALIT) K(fmak, OP_FMAK) 
 K(mad64, OP_MAD64) K(lshladd64, OP_LSHLADD64) K(lshl64, OP_LSHL64)
 K(fma, OP_FMA) K(mullo, OP_MULLO) K(mul24, OP_MUL24) K(mad24, OP_MAD24) K(xorb, OP_XOR) K(lshr, OP_LSHR) K(lshladd, OP_LSHLADD) K(addu, OP_ADDU)
 K(cvt, OP_CVT) K(rcp, OP_RCP) K(rsq, OP_RSQ) K(mov, OP_MOV) K(bfe, OP_BFE) K(andor, OP_ANDOR)
-template <typename F> void run(const char* name, F kern, float* d)
+template <typename F> void run(const char* name, F kern, float* d, unsigned long long* clocks)
 {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int blocks = 256 * 8; // 8 waves per SIMD
-    kern<<<blocks, 256>>>(d, 1.0001f); hipDeviceSynchronize();
-    hipEventRecord(e0); kern<<<blocks, 256>>>(d, 1.0001f); hipEventRecord(e1); hipEventSynchronize(e1);
+    kern<<<blocks, 256>>>(d, 1.0001f, N_ITER, clocks); hipDeviceSynchronize();
+    hipEventRecord(e0); kern<<<blocks, 256>>>(d, 1.0001f, N_ITER, clocks); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    double waveInstr = (double)blocks * 4 * N_ITER * 8;
-    printf("%-14s %7.3f ms  -> %5.2f cycles per wave64 instruction per SIMD (at 2.4 GHz)\n", name, ms, ms * 1e-3 * 2.4e9 * 1024 / waveInstr);
+    const int iters = (int)(N_ITER * (22.0 / (ms > 0.01f ? ms : 0.01f))) + N_ITER; /* >= 20 ms */
+    hipEventRecord(e0); kern<<<blocks, 256>>>(d, 1.0001f, iters, clocks); hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h[2]; hipMemcpy(h, clocks, sizeof(h), hipMemcpyDeviceToHost);
+    const double ghz = (double)h[0] / ((double)h[1] / 100e6) / 1e9; /* shader cycles / seconds of the 100 MHz counter, wave 0's life */
+    double waveInstr = (double)blocks * 4 * (double)iters * 8;
+    printf("%-14s %8.3f ms  clock %.3f GHz -> %5.2f cycles per wave64 instruction per SIMD\n", name, ms, ghz, ms * 1e-3 * ghz * 1e9 * 1024 / waveInstr);
+    fflush(stdout);
 }
 int main()
 {
     float* d; hipMalloc(&d, 256 * 8 * 256 * 4);
-#define R(n) run(#n, k_##n, d);
+    unsigned long long* clocks; hipMalloc(&clocks, 16);
+#define R(n) run(#n, k_##n, d, clocks);
     R(mad64) R(lshladd64) R(lshl64) R(mul) R(mullit) R(addlit) R(fmalit) R(fmak) R(mulinl) R(fmac) R(muls) R(sub) R(fma) R(fmas) R(pkmul) R(pkmuls) R(pkadd) R(pkfma) R(pkfmas) R(min) R(max) R(min3) R(max3) R(med3) R(cnd) R(cnds) R(cmp) R(cmps) R(minu) R(maxi) R(mul64) R(subs) R(mulneg) R(maxabs) R(mov) R(xorb) R(lshr) R(lshladd) R(addu) R(bfe) R(andor) R(mullo) R(mul24) R(mad24) R(cvt) R(rcp) R(rsq)
     return 0;
 }
