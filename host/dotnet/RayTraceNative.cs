@@ -170,6 +170,8 @@ namespace RayTraceHost
         [DllImport(Lib)] public static extern int rt_multi_peer_access(IntPtr multi, out int pairs, out int enabled);
         [DllImport(Lib)] public static extern int rt_gather_accumulated_to_device(IntPtr multi, int root, IntPtr d_rgba, UIntPtr bytes);
         [DllImport(Lib)] public static extern int rt_gather_frame_to_device(IntPtr multi, int root, IntPtr d_rgba, UIntPtr bytes);
+        // one process per GPU: the per-tile buffers gathered over a caller-owned ncclComm_t (RCCL over xGMI), de-interleaved on root
+        [DllImport(Lib)] public static extern int rt_gather_rccl(IntPtr ctx, IntPtr nccl_comm, int root, int use_accumulated, IntPtr d_rgba, UIntPtr bytes);
         // the rest of include/rt_abi.h (display blit, checkpoint, caller stream / caller-owned targets, statistics, the other builders)
         [DllImport(Lib)] public static extern IntPtr rt_version();
         [DllImport(Lib)] public static extern int rt_set_stream(IntPtr ctx, IntPtr hip_stream);

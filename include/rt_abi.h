@@ -377,6 +377,18 @@ void rt_build_bvh_gpu_release(void);
 /* RCM:183-190 UpdateCameraParams: fills viewParams from (fovDeg, aspect, focusDist). */
 int rt_camera_view_params(float fov_deg, float aspect, float focus_distance, float out_view_params[3]);
 
+/* ---- one process per GPU: the gather of the per-tile buffers over RCCL ----
+ * The reference is single-GPU; this is the exchange step of the row-tiled multi-GPU form (BASELINE.json north_star: "a final
+ * RCCL gather over xGMI of the per-tile accumulation buffer").  Every rank of the caller's communicator calls it with its
+ * partitioned context (rt_set_partition(strip_rows, rank, world_size)): the packed tiles travel to `root` with ncclSend /
+ * ncclRecv inside one group on the context's stream and are de-interleaved there into d_rgba (root only: H*W*16 bytes of
+ * device memory on root's GPU, row 0 = bottom like every render target here; other ranks pass NULL / 0).
+ * nccl_comm = a caller-owned ncclComm_t whose user rank / size are the context's partition index / count (checked).
+ * use_accumulated 1 = AccumulatedRender, 0 = FrameRender.  Synchronous: returns when the image (root) / the send (others)
+ * has completed.  RCCL (librccl.so) is loaded on first use; the library has no link-time dependency on it — without RCCL
+ * the call fails with RT_ERR_STATE and everything else works. */
+int rt_gather_rccl(RtContext* ctx, void* nccl_comm, int root, int use_accumulated, void* d_rgba, size_t bytes);
+
 /* ---- test hooks: the kernel's device functions on caller-supplied inputs ---- */
 /* CalculateRayCollision (RC:335-374) for n world rays (origins/dirs: n*3 floats,
  * host memory). out10 per ray: didHit, isBackface, dst, normal.xyz, pos.xyz,

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <dlfcn.h>
 #include <sys/mman.h>
 
 #include <cmath>
@@ -22,6 +23,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 
@@ -2486,6 +2488,107 @@ int rt_gather_accumulated_to_device(RtMulti* m, int root, void* d_rgba, size_t b
 int rt_gather_frame_to_device(RtMulti* m, int root, void* d_rgba, size_t bytes) { return multi_gather_device(m, root, d_rgba, bytes, false); }
 int rt_gather_accumulated(RtMulti* m, float* rgba, size_t bytes) { return multi_gather(m, rgba, bytes, true); }
 int rt_gather_frame(RtMulti* m, float* rgba, size_t bytes) { return multi_gather(m, rgba, bytes, false); }
+
+/* ---- RCCL, loaded on first use (no link-time dependency): the handful of entry points rt_gather_rccl needs */
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*CommUserRank)(void*, int*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+Rccl* rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {getenv("RT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            if (!n) continue;
+            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) return;
+        r.GroupStart = (int (*)())dlsym(r.lib, "ncclGroupStart");
+        r.GroupEnd = (int (*)())dlsym(r.lib, "ncclGroupEnd");
+        r.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(r.lib, "ncclSend");
+        r.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(r.lib, "ncclRecv");
+        r.CommCount = (int (*)(void*, int*))dlsym(r.lib, "ncclCommCount");
+        r.CommUserRank = (int (*)(void*, int*))dlsym(r.lib, "ncclCommUserRank");
+        r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
+        r.ok = r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.CommCount && r.CommUserRank;
+    });
+    return &r;
+}
+} // namespace
+
+int rt_gather_rccl(RtContext* ctx, void* nccl_comm, int root, int use_accumulated, void* d_rgba, size_t bytes)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_FLUSH(ctx);
+    if (!nccl_comm) return fail(ctx, RT_ERR_INVALID_ARG, "rt_gather_rccl: null communicator");
+    if (ctx->W == 0) return fail(ctx, RT_ERR_STATE, "rt_gather_rccl before rt_resize");
+    Rccl* R = rccl();
+    if (!R->ok) return fail(ctx, RT_ERR_STATE, "rt_gather_rccl: librccl.so could not be loaded (%s)", R->lib ? "missing symbols" : "dlopen failed; RT_RCCL_LIB names another path");
+    int world = 0, rank = -1;
+    if (R->CommCount(nccl_comm, &world) != 0 || R->CommUserRank(nccl_comm, &rank) != 0) return fail(ctx, RT_ERR_INVALID_ARG, "rt_gather_rccl: not a communicator");
+    if (world != ctx->partCount || rank != ctx->partIndex)
+        return fail(ctx, RT_ERR_STATE, "rt_gather_rccl: communicator rank %d of %d, context partition %d of %d", rank, world, ctx->partIndex, ctx->partCount);
+    if (root < 0 || root >= world) return fail(ctx, RT_ERR_INVALID_ARG, "rt_gather_rccl: root %d out of range", root);
+    const int W = ctx->W, H = ctx->H;
+    const bool isRoot = rank == root;
+    if (isRoot && (!d_rgba || bytes != (size_t)W * H * 16)) return fail(ctx, RT_ERR_INVALID_ARG, "rt_gather_rccl: bytes %zu != H*W*16 = %zu", bytes, (size_t)W * H * 16);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = joined(ctx);
+    const float* src = use_accumulated ? (ctx->boundAccum ? ctx->boundAccum : ctx->ownAccum) : (ctx->boundFrame ? ctx->boundFrame : ctx->ownFrame);
+    /* root: one staging area for every rank's packed tile (H rows in all), in the display scratch */
+    std::vector<size_t> rowOff(world + 1, 0);
+    for (int r = 0; r < world; r++) rowOff[r + 1] = rowOff[r] + (size_t)local_rows_for(H, ctx->stripRows, r, world);
+    char* staging = nullptr;
+    if (isRoot) {
+        void* p = nullptr;
+        const int rc = display_scratch(ctx, rowOff[world] * (size_t)W * 16, &p);
+        if (rc) return rc;
+        staging = (char*)p;
+    }
+    auto check = [&](int e, const char* what) -> int {
+        if (e == 0) return RT_OK;
+        return fail(ctx, RT_ERR_HIP, "rt_gather_rccl: %s: %s", what, R->GetErrorString ? R->GetErrorString(e) : "RCCL error");
+    };
+    /* every rank sends its tile to root, root receives from every rank — its own included, so that a one-rank communicator runs the
+     * same code; one group: the transfers progress together */
+    int rc = check(R->GroupStart(), "ncclGroupStart");
+    if (rc) return rc;
+    int e = 0;
+    if (ctx->localRows) e = R->Send(src, (size_t)ctx->localRows * W * 4, /*ncclFloat32*/ 7, root, nccl_comm, st);
+    if (isRoot)
+        for (int r = 0; r < world && e == 0; r++) {
+            const size_t rows = rowOff[r + 1] - rowOff[r];
+            if (rows) e = R->Recv(staging + rowOff[r] * (size_t)W * 16, rows * W * 4, 7, r, nccl_comm, st);
+        }
+    const int eEnd = R->GroupEnd();
+    if ((rc = check(e, "ncclSend / ncclRecv"))) return rc;
+    if ((rc = check(eEnd, "ncclGroupEnd"))) return rc;
+    if (isRoot)
+        for (int r = 0; r < world; r++) {
+            const int rows = (int)(rowOff[r + 1] - rowOff[r]);
+            if (!rows) continue;
+            size_t n = (size_t)rows * W;
+            int blocks = (int)((n + 255) / 256);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(rtk::rt_unpack_strips_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)(staging + rowOff[r] * (size_t)W * 16), (float4*)d_rgba, W, rows,
+                               ctx->stripRows, r, world);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    flush_timer(ctx);
+    return RT_OK;
+}
 
 int rt_multi_get_counters(RtMulti* m, RtCounters* out)
 {

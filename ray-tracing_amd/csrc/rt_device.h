@@ -53,12 +53,29 @@
 #define RT_CODE_MAX_INLINE_COUNT 127
 #define RT_CODE_MAX_INLINE_START 0x00ffffffu
 
+#ifdef RT_PAIR_FETCH
+/* two 32-byte halves, one child each: (min.xyz, code | max.xyz, -) — what ONE lane of a pair fetches in the pair-cooperative
+ * inner step (rt_kernels.h) */
+struct DPair {
+    float aMin[3];
+    uint32_t codeA;
+    float aMax[3];
+    uint32_t pad0;
+    float bMin[3];
+    uint32_t codeB;
+    float bMax[3];
+    uint32_t pad1;
+};
+#define RT_PAIR_FORMAT 1
+#else
 struct DPair {
     float aMin[3], aMax[3];
     float bMin[3], bMax[3];
     uint32_t codeA, codeB;
     uint32_t pad[2];
 };
+#define RT_PAIR_FORMAT 0
+#endif
 struct DTri {
     float ax, ay, az, abx;
     float aby, abz, acx, acy;

@@ -627,6 +627,97 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
             /* a short burst of inner steps per vote won (lanes that reach a leaf or run out of nodes
              * wait for the next vote): 3 measured best — 1 pays a vote per step, "until no lane
              * is at an inner node" (the classic while-while) idles most lanes most of the time */
+#ifdef RT_PAIR_FETCH
+            /* PAIR-COOPERATIVE inner step (round 5).  The BVH kernels are bound by the vector-memory path: 0.83-0.92 L1 accesses per clock
+             * per CU (profiles/r05_memory_path.txt) — a wave64 load costs the TA / L1 one access per group of neighbouring lanes that fall
+             * into one 128-byte line (tools/ubench/vmem_gather.hip), and an inner step is four loads per lane from one 64-byte record: four
+             * accesses per ray.  Here the two lanes of a pair (2m, 2m+1) fetch each node TOGETHER: in round j they both address the record
+             * of the pair's lane j, lane p reading the 32 bytes of child p (rt_device.h: the record is two halves, one child box + code
+             * each) — one access per load for the pair — and lane p does child p's slab test for BOTH rays (the owner's local ray comes
+             * through DPP operands), i.e. two box tests per lane as before.  One distance and one code per child then cross the pair
+             * (four selects + two DPP moves).  Same boxes, same tests, same order of the results: RC:262-282 to the bit. */
+#pragma clang loop unroll(disable)
+            for (int burst = 0; burst < RT_INNER_BURST; burst++) {
+                const bool mine = t.cur < RT_CODE_DONE;
+                /* who works in which round is decided on scalar masks (no VALU): round j runs for the pairs whose lane j is at an inner node */
+                const unsigned long long mMine = __ballot(mine);
+                const unsigned long long mEven = mMine & 0x5555555555555555ull, mOdd = mMine & 0xAAAAAAAAAAAAAAAAull;
+                const unsigned long long mAct0 = mEven | (mEven << 1), mAct1 = mOdd | (mOdd >> 1);
+                const bool odd = __builtin_amdgcn_inverse_ballot_w64(0xAAAAAAAAAAAAAAAAull);
+                /* quad_perm selectors: the pair's lane 0 / lane 1 / the partner */
+                constexpr int SEL0 = 0xA0 /* [0,0,2,2] */, SEL1 = 0xF5 /* [1,1,3,3] */, SELX = 0xB1 /* [1,0,3,2] */;
+#define RT_DPP_I(v, sel) __builtin_amdgcn_update_dpp(0, (int)(v), sel, 0xf, 0xf, true)
+#define RT_DPP_F(v, sel) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(v)), sel, 0xf, 0xf, true))
+                if (__builtin_amdgcn_inverse_ballot_w64(mAct0 | mAct1)) {
+                    const uint32_t offMine = (uint32_t)(t.cur << 4);
+                    const uint32_t halfOff = odd ? 32u : 0u;
+                    float D0 = RT_INF, D1 = RT_INF;
+                    uint32_t C0 = 0u, C1 = 0u;
+#if RT_PAIR_FETCH == 2 /* variant: both rounds' loads first (the second pair in flight while the first box is tested) — 35 spilled VGPRs at the 80-register budget */
+                    float4 lo0, hi0, lo1, hi1; /* written and read under the same masks */
+                    if (__builtin_amdgcn_inverse_ballot_w64(mAct0)) { /* round 0: the node of the pair's lane 0 */
+                        const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pairs) + ((uint32_t)RT_DPP_I(offMine, SEL0) + halfOff));
+                        lo0 = q[0];
+                        hi0 = q[1];
+                    }
+                    if (__builtin_amdgcn_inverse_ballot_w64(mAct1)) { /* round 1: the node of the pair's lane 1 */
+                        const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pairs) + ((uint32_t)RT_DPP_I(offMine, SEL1) + halfOff));
+                        lo1 = q[0];
+                        hi1 = q[1];
+                    }
+#endif
+                    if (__builtin_amdgcn_inverse_ballot_w64(mAct0)) {
+#if RT_PAIR_FETCH != 2
+                        const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pairs) + ((uint32_t)RT_DPP_I(offMine, SEL0) + halfOff));
+                        const float4 lo0 = q[0], hi0 = q[1];
+#endif
+                        const rt_f3 pos = rt_v3(RT_DPP_F(t.lpos.x, SEL0), RT_DPP_F(t.lpos.y, SEL0), RT_DPP_F(t.lpos.z, SEL0));
+                        const rt_f3 inv = rt_v3(RT_DPP_F(t.linv.x, SEL0), RT_DPP_F(t.linv.y, SEL0), RT_DPP_F(t.linv.z, SEL0));
+                        const float bmin[3] = {lo0.x, lo0.y, lo0.z}, bmax[3] = {hi0.x, hi0.y, hi0.z};
+                        D0 = box_dst(pos, inv, bmin, bmax);
+                        C0 = __float_as_uint(lo0.w);
+                    }
+                    if (__builtin_amdgcn_inverse_ballot_w64(mAct1)) {
+#if RT_PAIR_FETCH != 2
+                        const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pairs) + ((uint32_t)RT_DPP_I(offMine, SEL1) + halfOff));
+                        const float4 lo1 = q[0], hi1 = q[1];
+#endif
+                        const rt_f3 pos = rt_v3(RT_DPP_F(t.lpos.x, SEL1), RT_DPP_F(t.lpos.y, SEL1), RT_DPP_F(t.lpos.z, SEL1));
+                        const rt_f3 inv = rt_v3(RT_DPP_F(t.linv.x, SEL1), RT_DPP_F(t.linv.y, SEL1), RT_DPP_F(t.linv.z, SEL1));
+                        const float bmin[3] = {lo1.x, lo1.y, lo1.z}, bmax[3] = {hi1.x, hi1.y, hi1.z};
+                        D1 = box_dst(pos, inv, bmin, bmax);
+                        C1 = __float_as_uint(lo1.w);
+                    }
+                    /* lane p holds child p of both nodes: the result for its own node stays, the other crosses the pair */
+                    const float keepD = odd ? D1 : D0, giveD = odd ? D0 : D1;
+                    const uint32_t keepC = odd ? C1 : C0, giveC = odd ? C0 : C1;
+                    const float gotD = RT_DPP_F(giveD, SELX);
+                    const uint32_t gotC = (uint32_t)RT_DPP_I(giveC, SELX);
+                    if (mine) { /* ---- B: one inner node, RC:262-282 */
+                        if (STATS && !t.rootStep) st.inner++;
+                        t.rootStep = false;
+                        phase_mark<STATS>(st, PH_INNER);
+                        const float dstA = odd ? gotD : keepD, dstB = odd ? keepD : gotD;
+                        const uint32_t codeA = odd ? gotC : keepC, codeB = odd ? keepC : gotC;
+                        bool isNearestA = dstA <= dstB;
+                        float dstNear = isNearestA ? dstA : dstB;
+                        float dstFar = isNearestA ? dstB : dstA;
+                        uint32_t codeNear = isNearestA ? codeA : codeB;
+                        uint32_t codeFar = isNearestA ? codeB : codeA;
+                        if (dstNear < h.dst) {
+                            if (dstFar < h.dst) { stackBase[t.sp * RT_WAVE] = codeFar; t.sp++; }
+                            t.cur = codeNear;
+                        } else if (t.sp == 0) {
+                            t.cur = RT_CODE_NEXT_MODEL;
+                        } else {
+                            t.cur = stackBase[(--t.sp) * RT_WAVE];
+                        }
+                    }
+                }
+#undef RT_DPP_I
+#undef RT_DPP_F
+            }
+#else
 #pragma clang loop unroll(disable)
             for (int burst = 0; burst < RT_INNER_BURST; burst++)
             if (t.cur < RT_CODE_DONE) { /* ---- B: one inner node, RC:262-282 */
@@ -691,6 +782,7 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
                     t.cur = stackBase[(--t.sp) * RT_WAVE];
                 }
             }
+#endif
         } else if (atLeaf) { /* ---- C: one leaf, RC:248-261 */
             uint32_t count = (t.cur >> 24) & 0x7fu;
             uint32_t start = t.cur & RT_CODE_MAX_INLINE_START;
@@ -1395,6 +1487,18 @@ __global__ void rt_accumulate_kernel(const float4* staging, int nFrames, size_t 
 }
 
 /* ResetAccumulated — RCC:26-32 */
+/* rt_gather_rccl: rank `part`'s packed tile (its cyclic strips, local rows 0..rows-1) -> those rows of the whole image */
+__global__ void rt_unpack_strips_kernel(const float4* __restrict__ packed, float4* __restrict__ image, int W, int rows, int stripRows, int part, int parts)
+{
+    const size_t n = (size_t)rows * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(i / W), x = (int)(i - (size_t)l * W);
+        const int ls = l / stripRows;
+        const int g = (ls * parts + part) * stripRows + (l - ls * stripRows); /* rt_local_to_global_row */
+        image[(size_t)g * W + x] = packed[i];
+    }
+}
+
 __global__ void rt_reset_kernel(float4* accum, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -103,7 +103,7 @@ struct RtLayout {
 };
 
 #ifndef RT_LAYOUT_DEFAULT
-#define RT_LAYOUT_DEFAULT "dense"
+#define RT_LAYOUT_DEFAULT "pre,arena"
 #endif
 
 /* unknown words are an error (returns false): a mistyped A/B run must not silently measure the default */

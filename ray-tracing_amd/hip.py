@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "rt_multi_update_models", "rt_multi_update_spheres", "rt_multi_set_params", "rt_multi_reset_accumulation",
     "rt_multi_render_frame", "rt_multi_render_frames", "rt_multi_synchronize", "rt_gather_accumulated", "rt_gather_frame",
     "rt_multi_get_counters", "rt_multi_last_gather_ms", "rt_multi_peer_access", "rt_gather_accumulated_to_device", "rt_gather_frame_to_device",
+    "rt_gather_rccl",
 ]
 
 
@@ -77,6 +78,7 @@ class HipApi(abi.CApi):
         "multi_peer_access": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "gather_accumulated_to_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
         "gather_frame_to_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+        "gather_rccl": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     }
 
     def __init__(self, path=LIB_PATH):
@@ -319,6 +321,11 @@ class HipTracer(abi.Tracer):
         f, a = C.c_void_p(), C.c_void_p()
         self._check(self.api.get_render_targets(self.h, C.byref(f), C.byref(a)))
         return f.value, a.value
+
+    def gather_rccl(self, nccl_comm, root, device_ptr, nbytes, accumulated=True):
+        """rt_gather_rccl: this rank's packed tile to `root` over the caller's ncclComm_t (RCCL), de-interleaved into the whole image
+        at device_ptr on root (others pass None / 0)."""
+        self._check(self.api.gather_rccl(self.h, nccl_comm, int(root), 1 if accumulated else 0, device_ptr, nbytes))
 
     def synchronize(self):
         self._check(self.api.synchronize(self.h))

@@ -135,6 +135,55 @@ def test_bench_one_rank_through_rccl():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg,w,h", [(2, 200, 77), (3, 96, 54)])
+def test_gather_over_a_caller_owned_rccl_communicator(pkg, api, orc, cfg, w, h):
+    """rt_gather_rccl (the C ABI's own RCCL gather, no torch): a one-rank communicator made with librccl's ncclCommInitAll, the
+    context partitioned 1/1 — ncclGroupStart, a send and a receive of the packed tile, ncclGroupEnd, the de-interleave kernel —
+    and the gathered image equals the context's own read-back and the oracle's image.  Wrong communicators are refused."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    rccl = C.CDLL("librccl.so.1")
+    comm = C.c_void_p()
+    dev = (C.c_int * 1)(0)
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, dev) == 0
+    try:
+        tr = api.create_tracer(0)
+        tr.set_partition(8, 0, 1)
+        mgr = pkg.scenes.get(cfg).make_manager(tr, api, w, h)
+        mgr.OnEnable(renderSeed=5)
+        mgr.RenderFrames(3)
+        out = torch.full((h, w, 4), -1.0, dtype=torch.float32, device="cuda:0")
+        tr.gather_rccl(comm, 0, out.data_ptr(), out.numel() * 4, accumulated=True)
+        got = out.cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), tr.read_accumulated().view(np.uint32))
+        frame = torch.empty_like(out)
+        tr.gather_rccl(comm, 0, frame.data_ptr(), frame.numel() * 4, accumulated=False)
+        assert np.array_equal(frame.cpu().numpy().view(np.uint32), tr.read_frame().view(np.uint32))
+        ref = orc.create_tracer(8)
+        m2 = pkg.scenes.get(cfg).make_manager(ref, orc, w, h)
+        m2.OnEnable(renderSeed=5)
+        m2.RenderFrames(3)
+        assert np.array_equal(got.view(np.uint32), ref.read_accumulated().view(np.uint32))
+        ref.close()
+        # the communicator's rank / size must be the context's partition
+        tr2 = api.create_tracer(0)
+        tr2.set_partition(8, 0, 2)
+        tr2.resize(w, h)
+        with pytest.raises(pkg.abi.RtError):
+            tr2.gather_rccl(comm, 0, out.data_ptr(), out.numel() * 4)
+        tr2.close()
+        with pytest.raises(pkg.abi.RtError):
+            tr.gather_rccl(comm, 0, out.data_ptr(), 16)        # wrong size
+        with pytest.raises(pkg.abi.RtError):
+            tr.gather_rccl(None, 0, out.data_ptr(), out.numel() * 4)
+        tr.close()
+    finally:
+        rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.gpu
 def test_multi_context_peer_access_is_reported(pkg, api):
     """rt_create_multi checks / enables peer access between its distinct devices and says how device-to-device copies travel."""
     import ctypes as C
