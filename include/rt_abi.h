@@ -207,7 +207,9 @@ int rt_upload_scene(RtContext* ctx,
  * rt_last_error(NULL)); out_info (may be NULL) describes what would be uploaded.  For hosts that want to check a scene
  * before they own a GPU, and for the host-side tests. */
 typedef struct RtSceneInfo {
-    int32_t n_pairs;        /* sibling-pair records (64 bytes each) the traversal would fetch from */
+    int32_t n_pairs;        /* sibling-pair records (64 bytes each) the traversal would fetch from: an UPPER BOUND — meshes converted by
+                             * parallel workers get windows of the canonical array with slack between them (the uploaded pair space is
+                             * compacted by every layout but `dense`) */
     int32_t max_height;     /* deepest BVH, in levels below a root: the traversal stack the scene needs */
     int32_t flat;           /* 1: every model's root is a leaf (no traversal stack at all) */
     int32_t n_filtered;     /* models behind the conservative root filter */
@@ -426,6 +428,10 @@ void rt_debug_layout_free(RtLayoutDump* dump);
  * 11 pixel refill). n must be >= 24; if n >= 25, out[24] = number of times the conservative
  * world-space root filter rejected a model the exact root step would have entered (must be 0). */
 int rt_debug_phase_profile(RtContext* ctx, uint64_t* out, int n);
+
+/* Frames the context would put into one fused launch right now (16 ... 64: a budget that follows the measured frame time, see
+ * rt_context.hip RT_FUSE_MIN; scheduling only, results never depend on it). */
+int rt_debug_fused_frames_cap(const RtContext* ctx);
 
 /* Library identification: returns "raytrace_hip gfx950 abi=<n>" */
 const char* rt_version(void);

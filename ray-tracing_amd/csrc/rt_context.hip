@@ -27,18 +27,16 @@
 #include <thread>
 #include <unordered_map>
 
-#ifdef RT_WG_EXPERIMENT /* make wg: the queued stages with the parked chains in a workgroup-wide LDS pool (experiments/rt_kernels_wg.h) */
-#define RT_QUEUED_EXPERIMENT
-#include "experiments/rt_kernels_wg.h"
-#elif defined(RT_QUEUED_EXPERIMENT) /* make queued: the queued-stages form of the trace kernel, measured 3x slower */
-#include "experiments/rt_kernels_q.h"
-#else
 #include "rt_kernels.h"
-#endif
 
-#ifndef RT_MAX_FUSED_FRAMES
-#define RT_MAX_FUSED_FRAMES 16
-#endif
+/* Frames per fused launch: a budget, not a constant.  A launch ends with a tail as long as one pixel chain, so short
+ * frames want many per launch (a rank that renders 1/8 of config 2: 0.108 ms per frame, 7.9 work items per resident wave at 16 frames);
+ * long frames must not turn into launches that last seconds.  RT_FUSE_MIN frames always; more — up to RT_FUSE_MAX — while the launch
+ * stays under RT_FUSE_TARGET_MS at the frame time MEASURED on the previous fused launches (stop-event to stop-event, polled, never
+ * waited for).  BVH scenes (>= 4 ms per frame) stay at 16.  RT_FUSE_CAP=n pins it. */
+#define RT_FUSE_MIN 16
+#define RT_FUSE_MAX 64
+#define RT_FUSE_TARGET_MS 9.0
 #include "rt_layout.h"
 #define RT_VERSION_STRING "raytrace_hip gfx950 abi=1"
 
@@ -52,9 +50,6 @@ struct RtContext {
      * frame is launched as two kernels over disjoint halves of the tiles, one per stream, so that
      * the drain of one kernel overlaps the other instead of idling the chip. */
     hipStream_t sideStream = nullptr;
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
-    bool sideDirty = false; /* sideStream holds work the main stream has not been ordered after */
-    bool needFork = true;   /* the main stream holds non-render work the side stream must follow */
     bool twoStreams = true; /* RT_TWO_STREAMS=0: one kernel per launch on the main stream */
     char err[512] = {0};
 
@@ -111,42 +106,29 @@ struct RtContext {
     uint32_t* dTileOrder[2] = {nullptr, nullptr};
     uint32_t* dTileKey = nullptr;   /* the sort's snapshot of the costs (kernels in flight keep raising them) */
     int orderCur = 0;
-    hipEvent_t evSort = nullptr;    /* after the last sort; sortPending[s]: stream s has not been ordered after it yet */
-    bool sortPending[2] = {false, false};
-    hipEvent_t evOrderRetire[2] = {nullptr, nullptr}; /* recorded on the OTHER stream when the order buffer went out of use: its next rewrite waits for it */
-    bool retireValid[2] = {false, false};
     int orderTiles = 0;             /* tiles the two arrays are sized for; 0 = none */
     bool orderValid = false;
     long long framesSinceResize = 0;
     long long nextSortAt = 1;
     bool lptEnabled = true;
-    /* EXPERIMENT RT_XCD_AFFINITY=1|2 (fused launches): per-XCD ranges of the tile queue (KArgs::xcdQueues); 2 = LPT off and a static
-     * order in which the eight ranges are eight compact blocks of the image (4 x 2) */
-    int xcdAffinity = 0;
-    unsigned long long* dXcdQueues = nullptr; /* 2 launch slots x 8 counters */
-    uint32_t* dBlockOrder = nullptr;
-    int blockOrderTiles = 0;
     int numCUs = 256;
     int occPerCU[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     size_t occBytes[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool verbose = false;
     /* rt_render_frame calls that arrive while earlier frames are still executing are held back (at most
-     * RT_MAX_FUSED_FRAMES) and leave as ONE fused launch at the next call that needs them (flush_pending) */
+     * fuseCap) and leave as ONE fused launch at the next call that needs them (flush_pending) */
     void* dPxCold = nullptr; /* pixel records of the resident waves: 2 launch slots (main / side stream) x pxColdWaves x 2 KB */
     long long pxColdWaves = 0;
-    /* queued-stages kernel form (rt_kernels_q.h): BVH scenes with up to 64 models */
-    bool queued = false;        /* RT_QUEUED=1 */
-    bool wg = false;            /* RT_WG=1: the workgroup form (make wg) */
-    int wgTravWaves = 6;        /* RT_WG_NT */
-    int qFlushMin = 16, qRefillMin = 16, qStarveMin = 32; /* RT_Q_FLUSH / RT_Q_REFILL / RT_Q_STARVE (scheduling only) */
-    void* dQRecords = nullptr;  /* 2 launch slots x qWaves x RT_Q_WAVE_DWORDS dwords */
-    long long qWaves = 0;
-    void* dWgRecords = nullptr; /* workgroup form: 2 launch slots x wgUnits x RT_WG_GLOBAL_DWORDS dwords of pixel records */
-    long long wgUnits = 0;
+    struct ExperimentState* exp = nullptr; /* host state of the kernel experiments; null in the product build (see RT_EXPERIMENTS below) */
     int frameGroupOverride = 0; /* RT_FRAME_GROUP: frames per (tile, frame group) item of fused launches (tuning hook) */
     bool coalesce = true;  /* RT_COALESCE=0: every rt_render_frame launches at once */
     int pending = 0;       /* frames [frame - pending, frame) requested but not launched yet */
-    bool fuseFrames = true; /* rt_render_frames(n): up to RT_MAX_FUSED_FRAMES frames per launch (RT_FUSE_FRAMES=0: one launch per frame) */
+    bool fuseFrames = true; /* rt_render_frames(n): up to fuseCap frames per launch (RT_FUSE_FRAMES=0: one launch per frame) */
+    int fuseCap = RT_FUSE_MIN;  /* frames per fused launch right now (see RT_FUSE_MIN) */
+    bool fuseCapPinned = false; /* RT_FUSE_CAP */
+    /* the stop event of each fused launch's trace kernel; ms per frame = (stop - previous launch's stop) / frames once both have passed */
+    struct FuseProbe { hipEvent_t stop = nullptr; int frames = 0; int prev = -1; bool live = false; } fuseProbe[6];
+    int fuseLast = -1;
     int gridOverride = 0; /* test hook: force the persistent grid size */
     bool stats = false;
     uint64_t pixelFrames = 0;
@@ -175,17 +157,30 @@ struct RtContext {
     size_t stagingBytes[2] = {0, 0};
     bool stagingUnavailable = false; /* the slab could not be allocated at this image size: fused launches go out frame by frame (cleared by rt_resize) */
     int stagedNext = 0;              /* stream / slab of the next fused launch */
-    bool alternate = true;           /* RT_ALTERNATE=0: every fused launch on the main stream (round-3 behaviour) */
-    /* the accumulation buffer is added to in launch order whichever stream a launch runs on: evAccWriter[s] marks the last
-     * kernel on stream s that writes it; accWriterPending[s] = the other stream has not been ordered after it yet */
-    hipEvent_t evAccWriter[2] = {nullptr, nullptr};
-    bool accWriterPending[2] = {false, false};
-    bool accWriterFull[2] = {false, false}; /* that kernel touches every pixel (an accumulate kernel, a one-part frame); false = one half of a two-part frame */
-    /* the last FULL writer of a stream is tracked on its own: a half kernel launched behind it on the same stream re-records
-     * evAccWriter[s] with full = false, and the other stream's half of that very frame would then no longer wait for the full
-     * writer (rt_render_frames(17): 16 fused frames + 1 two-part frame; found by tools/soak.py, round 4) */
-    hipEvent_t evAccFull[2] = {nullptr, nullptr};
-    bool accFullPending[2] = {false, false};
+    bool alternate = true;           /* fused launches alternate between the two streams; off while the second slab does not fit (until the next rt_resize) */
+    bool alternateWanted = true;     /* RT_ALTERNATE=0: every fused launch on the main stream (round-3 behaviour) */
+    /* ---- everything the context's two render streams wait for ACROSS each other, in one place (the rules: LaunchOrder's functions below)
+     * s = 0 the main stream, 1 the side stream */
+    struct Order {
+        hipEvent_t evFork = nullptr, evJoin = nullptr;
+        bool sideDirty = false; /* the side stream holds work the main stream has not been ordered after */
+        bool needFork = true;   /* the main stream holds non-render work the side stream must follow */
+        hipEvent_t evSort = nullptr;    /* after the last sort of the tile order; sortPending[s]: stream s has not been ordered after it yet */
+        bool sortPending[2] = {false, false};
+        hipEvent_t evOrderRetire[2] = {nullptr, nullptr}; /* per order buffer: recorded on the OTHER stream when the buffer went out of use; its next rewrite waits for it */
+        bool retireValid[2] = {false, false};
+        /* the accumulation buffer is added to in launch order whichever stream a launch runs on: evAccWriter[s] marks the last kernel on
+         * stream s that writes it; accWriterPending[s] = the other stream has not been ordered after it yet; accWriterFull[s] = that kernel
+         * touches every pixel (an accumulate kernel, a one-part frame; false = one half of a two-part frame) */
+        hipEvent_t evAccWriter[2] = {nullptr, nullptr};
+        bool accWriterPending[2] = {false, false};
+        bool accWriterFull[2] = {false, false};
+        /* the last WHOLE-IMAGE writer of a stream is tracked on its own: a half kernel launched behind it on the same stream re-records
+         * evAccWriter[s] with full = false, and the other stream's half of that very frame would then no longer wait for the whole-image
+         * writer (rt_render_frames(17): 16 fused frames + 1 two-part frame; found by tools/soak.py, round 4) */
+        hipEvent_t evAccFull[2] = {nullptr, nullptr};
+        bool accFullPending[2] = {false, false};
+    } ord;
     int lastLaunched = 0;            /* frames the last launch_frames call really enqueued (flush_pending rolls back the rest) */
     void* dDisplay = nullptr;  /* scratch of the display pass, kept between calls (grows on demand) */
     size_t displayBytes = 0;
@@ -217,14 +212,14 @@ static int fail(RtContext* ctx, int status, const char* fmt, ...)
  * use of the stream other than a render launch goes through here. */
 static hipStream_t joined(RtContext* ctx)
 {
-    if (ctx->sideDirty) {
-        hipEventRecord(ctx->evJoin, ctx->sideStream);
-        hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0);
-        ctx->sideDirty = false;
-        ctx->accWriterPending[1] = false; /* whatever the side stream adds to the accumulation buffer now precedes the main stream's next kernel */
-        ctx->accFullPending[1] = false;
+    if (ctx->ord.sideDirty) {
+        hipEventRecord(ctx->ord.evJoin, ctx->sideStream);
+        hipStreamWaitEvent(ctx->stream, ctx->ord.evJoin, 0);
+        ctx->ord.sideDirty = false;
+        ctx->ord.accWriterPending[1] = false; /* whatever the side stream adds to the accumulation buffer now precedes the main stream's next kernel */
+        ctx->ord.accFullPending[1] = false;
     }
-    ctx->needFork = true;
+    ctx->ord.needFork = true;
     return ctx->stream;
 }
 
@@ -284,6 +279,8 @@ static int stage_upload(RtContext* ctx, void* dst, const void* src, size_t bytes
 
 static int launch_frames(RtContext* ctx, int frame0, int nFrames);
 static bool gpu_idle(RtContext* ctx);
+static void exp_create(RtContext* ctx);
+static void exp_release(RtContext* ctx);
 
 /* Launch the frames rt_render_frame held back.  Called first thing by every entry point that reads or changes
  * what those frames depend on, or that hands results to the host. */
@@ -341,15 +338,15 @@ int rt_create(int device_id, RtContext** out)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->ownStream));
         HIP_TRY(ctx, hipEventCreate(&ctx->evStart));
         HIP_TRY(ctx, hipEventCreate(&ctx->evStop));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evAccWriter[0], hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evAccWriter[1], hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evAccFull[0], hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evAccFull[1], hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evSort, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evOrderRetire[0], hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->evOrderRetire[1], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ord.evFork, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ord.evJoin, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ord.evAccWriter[0], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ord.evAccWriter[1], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ord.evAccFull[0], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ord.evAccFull[1], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ord.evSort, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ord.evOrderRetire[0], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ord.evOrderRetire[1], hipEventDisableTiming));
         return RT_OK;
     };
     if (int rc = init()) { /* the message stays readable through rt_last_error(NULL) */
@@ -361,18 +358,15 @@ int rt_create(int device_id, RtContext** out)
     if (getenv("RT_VERBOSE")) ctx->verbose = true;
     if (const char* f = getenv("RT_FUSE_FRAMES")) ctx->fuseFrames = atoi(f) != 0;
     if (const char* l = getenv("RT_LPT")) ctx->lptEnabled = atoi(l) != 0;
-    if (const char* l = getenv("RT_XCD_AFFINITY")) ctx->xcdAffinity = atoi(l);
-    if (ctx->xcdAffinity == 2) ctx->lptEnabled = false;
     if (const char* t = getenv("RT_TWO_STREAMS")) ctx->twoStreams = atoi(t) != 0;
     if (const char* c = getenv("RT_COALESCE")) ctx->coalesce = atoi(c) != 0;
     if (const char* fg = getenv("RT_FRAME_GROUP")) ctx->frameGroupOverride = atoi(fg);
-    if (const char* al = getenv("RT_ALTERNATE")) ctx->alternate = atoi(al) != 0;
-    if (const char* q = getenv("RT_QUEUED")) ctx->queued = atoi(q) != 0;
-    if (const char* q = getenv("RT_WG")) ctx->wg = atoi(q) != 0;
-    if (const char* q = getenv("RT_WG_NT")) ctx->wgTravWaves = atoi(q);
-    if (const char* q = getenv("RT_Q_FLUSH")) ctx->qFlushMin = atoi(q);
-    if (const char* q = getenv("RT_Q_REFILL")) ctx->qRefillMin = atoi(q);
-    if (const char* q = getenv("RT_Q_STARVE")) ctx->qStarveMin = atoi(q);
+    if (const char* al = getenv("RT_ALTERNATE")) ctx->alternate = ctx->alternateWanted = atoi(al) != 0;
+    if (const char* fc = getenv("RT_FUSE_CAP")) {
+        const int v = atoi(fc);
+        if (v >= 1) { ctx->fuseCap = v > RT_FUSE_MAX ? RT_FUSE_MAX : v; ctx->fuseCapPinned = true; }
+    }
+    exp_create(ctx); /* the experiments' environment (nothing in the product build) */
     *out = ctx;
     return RT_OK;
 }
@@ -408,18 +402,15 @@ void rt_destroy(RtContext* ctx)
     hipFree(ctx->dTileOrder[0]);
     hipFree(ctx->dTileOrder[1]);
     hipFree(ctx->dTileKey);
-    hipFree(ctx->dXcdQueues);
-    hipFree(ctx->dBlockOrder);
-    if (ctx->evSort) hipEventDestroy(ctx->evSort);
-    for (int i = 0; i < 2; i++) if (ctx->evOrderRetire[i]) hipEventDestroy(ctx->evOrderRetire[i]);
+    if (ctx->ord.evSort) hipEventDestroy(ctx->ord.evSort);
+    for (int i = 0; i < 2; i++) if (ctx->ord.evOrderRetire[i]) hipEventDestroy(ctx->ord.evOrderRetire[i]);
     hipFree(ctx->dDisplay);
     hipFree(ctx->dStaging[0]);
     hipFree(ctx->dStaging[1]);
-    for (int i = 0; i < 2; i++) if (ctx->evAccWriter[i]) hipEventDestroy(ctx->evAccWriter[i]);
-    for (int i = 0; i < 2; i++) if (ctx->evAccFull[i]) hipEventDestroy(ctx->evAccFull[i]);
+    for (int i = 0; i < 2; i++) if (ctx->ord.evAccWriter[i]) hipEventDestroy(ctx->ord.evAccWriter[i]);
+    for (int i = 0; i < 2; i++) if (ctx->ord.evAccFull[i]) hipEventDestroy(ctx->ord.evAccFull[i]);
     hipFree(ctx->dPxCold);
-    hipFree(ctx->dQRecords);
-    hipFree(ctx->dWgRecords);
+    exp_release(ctx);
     for (auto& pr : ctx->tuner.probe) {
         if (pr.start) hipEventDestroy(pr.start);
         if (pr.stop) hipEventDestroy(pr.stop);
@@ -428,10 +419,11 @@ void rt_destroy(RtContext* ctx)
         if (st.host) hipHostFree(st.host);
         if (st.done) hipEventDestroy(st.done);
     }
+    for (auto& fp : ctx->fuseProbe) if (fp.stop) hipEventDestroy(fp.stop);
     if (ctx->evStart) hipEventDestroy(ctx->evStart);
     if (ctx->evStop) hipEventDestroy(ctx->evStop);
-    if (ctx->evFork) hipEventDestroy(ctx->evFork);
-    if (ctx->evJoin) hipEventDestroy(ctx->evJoin);
+    if (ctx->ord.evFork) hipEventDestroy(ctx->ord.evFork);
+    if (ctx->ord.evJoin) hipEventDestroy(ctx->ord.evJoin);
     if (ctx->sideStream) hipStreamDestroy(ctx->sideStream);
     if (ctx->ownStream) hipStreamDestroy(ctx->ownStream);
     delete ctx;
@@ -488,12 +480,16 @@ int rt_resize(RtContext* ctx, int width, int height)
     ctx->boundFrame = ctx->boundAccum = nullptr;
     ctx->orderTiles = 0; /* tile costs belong to the old geometry */
     for (int i = 0; i < 2; i++)
-        if (ctx->dStaging[i] && ctx->stagingBytes[i] != (size_t)RT_MAX_FUSED_FRAMES * ctx->localRows * width * 16) {
-            hipFree(ctx->dStaging[i]); /* sized for the old image (16 frames of it): re-made by the next fused launch */
+        if (ctx->dStaging[i]) {
+            hipFree(ctx->dStaging[i]); /* sized for the old image: re-made by the next fused launch */
             ctx->dStaging[i] = nullptr;
             ctx->stagingBytes[i] = 0;
         }
     ctx->stagingUnavailable = false;
+    ctx->alternate = ctx->alternateWanted; /* (a slab that did not fit the old image may fit this one: ADVICE r4) */
+    if (!ctx->fuseCapPinned) ctx->fuseCap = RT_FUSE_MIN; /* frame times of the old geometry say nothing */
+    for (auto& fp : ctx->fuseProbe) fp.live = false;
+    ctx->fuseLast = -1;
     return RT_OK;
 }
 
@@ -1479,111 +1475,192 @@ static void fill_args(RtContext* ctx, int frame0, int nFrames, KArgs& a)
     a.counters = ctx->dCounters;
 }
 
-static int launch_frames(RtContext* ctx, int frame0, int nFrames)
-{
-    KArgs a;
-    fill_args(ctx, frame0, nFrames, a);
-    const int tiles = a.tilesX * a.tilesY;
-    if (tiles == 0) return RT_OK;
-#ifdef RT_LDS_NODE_FETCH
-    const size_t slabBytes = 4 * RT_WAVE * 16; /* experiment: LDS-staged node fetch (rt_kernels.h) */
+} /* extern "C" */
+
+/* =====================================================================================================================
+ * The launch path.  rt_render_frame / rt_render_frames / flush_pending end in launch_frames(ctx, frame0, nFrames):
+ *     choose_variant    which kernel instantiation, how much LDS, how many workgroups the chip keeps resident (LaunchPlan)
+ *     prepare_*         the buffers a launch needs — pixel records, tile order, staging slab; may synchronise (rarely)
+ *     enqueue_*         kernels and events, in the order LaunchOrder's rules demand
+ * Dispatch semantics kept: RayComputeManager.cs:84-95 (one RayTrace dispatch per frame, Frame counts the accumulated frames).
+ * ===================================================================================================================== */
+struct LaunchPlan {
+    void (*kern)(const KArgs) = nullptr;     /* a launch that renders a whole frame or a batch of frames */
+    void (*kernHalf)(const KArgs) = nullptr; /* the same code under a second name: the two halves of a two-part frame (rt_kernels.h) */
+    size_t ldsBytes = 0;
+    int blockThreads = RT_WAVE;
+    int variant = 0;             /* slot of the occupancy cache */
+    bool twoPartsAllowed = true; /* (an experiment kernel may want one kernel per launch) */
+    long long resident = 0;      /* workgroups the chip keeps resident */
+};
+
+/* ---- the kernel experiments' host halves: ONE hook; the product build compiles the empty versions */
+#ifdef RT_EXPERIMENTS
+#include "experiments/rt_launch_experiments.inl"
+static void exp_create(RtContext* ctx) { ctx->exp = new ExperimentState(); exp_init(ctx, *ctx->exp); }
+static void exp_release(RtContext* ctx) { if (ctx->exp) { exp_destroy(*ctx->exp); delete ctx->exp; ctx->exp = nullptr; } }
 #else
-    const size_t slabBytes = 0;
+struct ExperimentState {};
+static void exp_create(RtContext*) {}
+static void exp_release(RtContext*) {}
+static int exp_choose(RtContext*, ExperimentState&, KArgs&, LaunchPlan&, bool) { return RT_OK; }
+static int exp_prepare(RtContext*, ExperimentState&, long long) { return RT_OK; }
+static int exp_pre_launch(RtContext*, ExperimentState&, KArgs&, int, hipStream_t, bool, int, bool* ownQueue) { *ownQueue = false; return RT_OK; }
+static int exp_post_launch(RtContext*, ExperimentState&, int, hipStream_t) { return RT_OK; }
 #endif
+static ExperimentState g_noExperiments;
+static inline ExperimentState& exp_of(RtContext* ctx) { return ctx->exp ? *ctx->exp : g_noExperiments; }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * LaunchOrder — every wait between the context's two render streams (s = 0 main, 1 side), as named steps.
+ *
+ *   what                          who writes it                     rule
+ *   non-render work (uploads,     the main stream, through           fork_side: before the side stream's next kernel it waits for evFork,
+ *    resets, read-backs)           joined()                          recorded on the main stream (needFork); joined() itself makes the main
+ *                                                                    stream wait for what the side stream holds (evJoin, sideDirty)
+ *   tile order buffer b           rt_order_kernel on stream ss       begin_sort: the rewrite of b waits for b's last readers on the other stream
+ *                                                                    (evOrderRetire[b]) and — the sorts share one key snapshot — for the previous
+ *                                                                    sort if that ran on the other stream; end_sort records evSort, marks the
+ *                                                                    other stream (sortPending) and retires the buffer going out of use;
+ *                                                                    before_order_read: a stream's next trace kernel waits for evSort once
+ *   accumulation buffer           single-frame trace kernels          before_acc_write(s, whole): wait for the OTHER stream's last whole-image
+ *                                  (whole image, or the half of a     writer (evAccFull) and, if this kernel or that stream's last writer covers
+ *                                  two-part frame), accumulate        the whole image, for its last writer of any kind (evAccWriter).  Halves of
+ *                                  kernels (whole image)              consecutive two-part frames need no wait: between two sorts a stream's half
+ *                                                                    is the same set of pixels — end_sort therefore declares both last writers
+ *                                                                    "whole".  after_acc_write records the events.
+ *   staging slab i, pixel         launches on stream i only          stream order (nothing here)
+ *    records i, tile counter i
+ * --------------------------------------------------------------------------------------------------------------------- */
+namespace LaunchOrder {
+static inline hipStream_t stream_of(RtContext* ctx, int s) { return s ? ctx->sideStream : ctx->stream; }
+
+static int fork_side(RtContext* ctx)
+{
+    if (!ctx->ord.needFork) return RT_OK;
+    HIP_TRY(ctx, hipEventRecord(ctx->ord.evFork, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->sideStream, ctx->ord.evFork, 0));
+    ctx->ord.needFork = false;
+    return RT_OK;
+}
+static void side_used(RtContext* ctx) { ctx->ord.sideDirty = true; }
+
+static int begin_sort(RtContext* ctx, int ss, int target)
+{
+    RtContext::Order& o = ctx->ord;
+    if (ss == 1) { int rc = fork_side(ctx); if (rc) return rc; }
+    hipStream_t S = stream_of(ctx, ss);
+    if (o.retireValid[target]) HIP_TRY(ctx, hipStreamWaitEvent(S, o.evOrderRetire[target], 0));
+    if (o.sortPending[ss]) HIP_TRY(ctx, hipStreamWaitEvent(S, o.evSort, 0)); /* (two sorts in consecutive launches on alternating streams) */
+    return RT_OK;
+}
+static int end_sort(RtContext* ctx, int ss, bool twoStreams, int retiring /* buffer going out of use, or -1 */)
+{
+    RtContext::Order& o = ctx->ord;
+    HIP_TRY(ctx, hipEventRecord(o.evSort, stream_of(ctx, ss)));
+    o.sortPending[ss] = false;
+    o.sortPending[1 - ss] = twoStreams;
+    if (retiring >= 0 && twoStreams) { /* whatever the other stream holds so far may still read it */
+        HIP_TRY(ctx, hipEventRecord(o.evOrderRetire[retiring], stream_of(ctx, 1 - ss)));
+        o.retireValid[retiring] = true;
+    }
+    if (ss == 1) side_used(ctx);
+    /* a new order moves pixels between the two halves of a two-part frame: the next such frame's halves must come after BOTH
+     * streams' last kernels that add into the accumulation buffer */
+    o.accWriterFull[0] = o.accWriterFull[1] = true;
+    return RT_OK;
+}
+static int before_order_read(RtContext* ctx, int s)
+{
+    if (!ctx->ord.sortPending[s]) return RT_OK;
+    HIP_TRY(ctx, hipStreamWaitEvent(stream_of(ctx, s), ctx->ord.evSort, 0));
+    ctx->ord.sortPending[s] = false;
+    return RT_OK;
+}
+static void forget_order(RtContext* ctx) /* the order buffers were re-made (another image size) */
+{
+    ctx->ord.sortPending[0] = ctx->ord.sortPending[1] = false;
+    ctx->ord.retireValid[0] = ctx->ord.retireValid[1] = false;
+}
+
+static int before_acc_write(RtContext* ctx, int s, bool whole)
+{
+    RtContext::Order& o = ctx->ord;
+    hipStream_t st = stream_of(ctx, s);
+    if (o.accFullPending[1 - s]) { /* once waited for, everything later on this stream follows it */
+        HIP_TRY(ctx, hipStreamWaitEvent(st, o.evAccFull[1 - s], 0));
+        o.accFullPending[1 - s] = false;
+    }
+    if (o.accWriterPending[1 - s] && (whole || o.accWriterFull[1 - s])) HIP_TRY(ctx, hipStreamWaitEvent(st, o.evAccWriter[1 - s], 0));
+    return RT_OK;
+}
+static int after_acc_write(RtContext* ctx, int s, bool whole)
+{
+    RtContext::Order& o = ctx->ord;
+    HIP_TRY(ctx, hipEventRecord(o.evAccWriter[s], stream_of(ctx, s)));
+    o.accWriterPending[s] = true;
+    o.accWriterFull[s] = whole;
+    if (whole) {
+        HIP_TRY(ctx, hipEventRecord(o.evAccFull[s], stream_of(ctx, s)));
+        o.accFullPending[s] = true;
+    }
+    return RT_OK;
+}
+/* a whole-image writer on stream s was ordered after everything the other stream wrote (before_acc_write(s, true)): later writers wait for it */
+static void other_stream_settled(RtContext* ctx, int s) { ctx->ord.accWriterPending[1 - s] = false; }
+} // namespace LaunchOrder
+
+/* ---- choose variant: kernel instantiation, LDS, resident workgroups */
+static int choose_variant(RtContext* ctx, KArgs& a, LaunchPlan& plan, bool* manyOut)
+{
     const size_t coldBytes = ctx->flatScene ? (size_t)2 * RT_WAVE * 16 : 0; /* the FLAT variant keeps its pixel records in LDS (rt_kernels.h, PX_COLD) */
-    const size_t stackBytes = (size_t)(ctx->stackEntries + RT_PIXEL_FIELDS + (ctx->extWords ? 2 + ctx->extWords : 0)) * RT_WAVE * sizeof(uint32_t) + slabBytes + coldBytes; /* mask extension: summary + words + the MANY variant's bounce row */
+    /* traversal stack + pixel fields + (more than 64 models) the mask extension: summary + words + the MANY variant's bounce row */
+    plan.ldsBytes = (size_t)(ctx->stackEntries + RT_PIXEL_FIELDS + (ctx->extWords ? 2 + ctx->extWords : 0)) * RT_WAVE * sizeof(uint32_t) + coldBytes;
     a.stackEntries = ctx->stackEntries;
     const bool many = ctx->nChunks > 0 && !ctx->flatScene;
-    void (*kern)(const KArgs) = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_kernel<true, true> : rtk::rt_trace_kernel<false, true>)
-                                : many         ? (ctx->stats ? rtk::rt_trace_kernel<true, false, true> : rtk::rt_trace_kernel<false, false, true>)
-                                               : (ctx->stats ? rtk::rt_trace_kernel<true, false> : rtk::rt_trace_kernel<false, false>);
-    /* the same code under a second name for the two-launches-per-frame form (see rt_kernels.h) */
-    void (*kernHalf)(const KArgs) = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_half_kernel<true, true> : rtk::rt_trace_half_kernel<false, true>)
-                                    : many         ? (ctx->stats ? rtk::rt_trace_half_kernel<true, false, true> : rtk::rt_trace_half_kernel<false, false, true>)
-                                                   : (ctx->stats ? rtk::rt_trace_half_kernel<true, false> : rtk::rt_trace_half_kernel<false, false>);
-    /* EXPERIMENT (make queued): the queued-stages form of the same kernel (rt_kernels_q.h) for BVH scenes with up to 64 models */
-#ifdef RT_QUEUED_EXPERIMENT
-    const bool queued = ctx->queued && !ctx->flatScene && !many;
-    if (queued) {
-        kern = ctx->stats ? rtk::rt_trace_q_kernel<true> : rtk::rt_trace_q_kernel<false>;
-        kernHalf = ctx->stats ? rtk::rt_trace_q_half_kernel<true> : rtk::rt_trace_q_half_kernel<false>;
-        a.qFlushMin = ctx->qFlushMin < 1 ? 1 : ctx->qFlushMin > 64 ? 64 : ctx->qFlushMin;
-        a.qRefillMin = ctx->qRefillMin < 1 ? 1 : ctx->qRefillMin > 64 ? 64 : ctx->qRefillMin;
-        a.qStarveMin = ctx->qStarveMin < 0 ? 0 : ctx->qStarveMin;
-    }
-#else
-    const bool queued = false;
-#endif
-    /* EXPERIMENT (make wg): eight-wave workgroups, traversal waves + shading waves around an LDS pool of parked chains */
-    size_t ldsBytes = stackBytes;
-    int blockThreads = RT_WAVE;
-#ifdef RT_WG_EXPERIMENT
-    const bool wgActive = ctx->wg && !ctx->flatScene && !many;
-    if (wgActive) {
-        kern = ctx->stats ? rtk::rt_trace_wg_kernel<true> : rtk::rt_trace_wg_kernel<false>;
-        kernHalf = kern;
-        a.wgTravWaves = ctx->wgTravWaves < 1 ? 1 : ctx->wgTravWaves > RT_WG_WAVES - 1 ? RT_WG_WAVES - 1 : ctx->wgTravWaves;
-        a.qFlushMin = ctx->qFlushMin < 1 ? 1 : ctx->qFlushMin > 64 ? 64 : ctx->qFlushMin;
-        a.qStarveMin = getenv("RT_Q_STARVE") ? (ctx->qStarveMin < 0 ? 0 : ctx->qStarveMin) : 64;
-        {   /* the largest pool that keeps three workgroups (24 waves) on a CU's 160 KB of LDS */
-            const size_t fixed = (size_t)a.wgTravWaves * ctx->stackEntries * RT_WAVE * sizeof(uint32_t) + sizeof(rtk::WgShared) + 16;
-            const size_t budget = 51 * 1024; /* 3 x 51 KB + allocation granules < 160 KB */
-            long long pool = budget > fixed ? (long long)((budget - fixed) / (RT_WG_REC * sizeof(uint32_t))) : 0;
-            if (const char* e = getenv("RT_WG_POOL")) pool = atoll(e);
-            a.wgPool = (int)(pool > RT_WG_POOL_MAX ? RT_WG_POOL_MAX : pool < 128 ? 128 : pool);
-        }
-        ldsBytes = ((size_t)a.wgTravWaves * ctx->stackEntries * RT_WAVE + (size_t)a.wgPool * RT_WG_REC) * sizeof(uint32_t) + sizeof(rtk::WgShared) + 16;
-        blockThreads = RT_WG_THREADS;
-    }
-#else
-    const bool wgActive = false;
-#endif
-    const int variant = wgActive ? 8 + (ctx->stats ? 1 : 0) : queued ? 6 + (ctx->stats ? 1 : 0) : (ctx->flatScene ? 2 : many ? 4 : 0) + (ctx->stats ? 1 : 0);
-    if (ctx->occBytes[variant] != ldsBytes + 1) { /* occupancy query cached per (variant, LDS bytes) */
+    *manyOut = many;
+    plan.kern = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_kernel<true, true> : rtk::rt_trace_kernel<false, true>)
+                : many         ? (ctx->stats ? rtk::rt_trace_kernel<true, false, true> : rtk::rt_trace_kernel<false, false, true>)
+                               : (ctx->stats ? rtk::rt_trace_kernel<true, false> : rtk::rt_trace_kernel<false, false>);
+    plan.kernHalf = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_half_kernel<true, true> : rtk::rt_trace_half_kernel<false, true>)
+                    : many         ? (ctx->stats ? rtk::rt_trace_half_kernel<true, false, true> : rtk::rt_trace_half_kernel<false, false, true>)
+                                   : (ctx->stats ? rtk::rt_trace_half_kernel<true, false> : rtk::rt_trace_half_kernel<false, false>);
+    plan.variant = (ctx->flatScene ? 2 : many ? 4 : 0) + (ctx->stats ? 1 : 0);
+    int rc = exp_choose(ctx, exp_of(ctx), a, plan, many);
+    if (rc) return rc;
+    if (ctx->occBytes[plan.variant] != plan.ldsBytes + 1) { /* occupancy query cached per (variant, LDS bytes) */
         int perCU = 0;
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, blockThreads, ldsBytes));
-        ctx->occPerCU[variant] = perCU > 0 ? perCU : 1;
-        ctx->occBytes[variant] = ldsBytes + 1;
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, plan.kern, plan.blockThreads, plan.ldsBytes));
+        ctx->occPerCU[plan.variant] = perCU > 0 ? perCU : 1;
+        ctx->occBytes[plan.variant] = plan.ldsBytes + 1;
         if (getenv("RT_DEBUG_LAUNCH"))
-            fprintf(stderr, "[rt] kernel variant %d: %d stack entries, %zu B of LDS per workgroup of %d threads, %d workgroups per CU\n", variant, ctx->stackEntries, ldsBytes, blockThreads, perCU);
+            fprintf(stderr, "[rt] kernel variant %d: %d stack entries, %zu B of LDS per workgroup of %d threads, %d workgroups per CU\n", plan.variant, ctx->stackEntries, plan.ldsBytes, plan.blockThreads, perCU);
     }
-    const long long resident = (long long)ctx->occPerCU[variant] * ctx->numCUs;
-    {
-        const long long waves = ctx->gridOverride > resident ? ctx->gridOverride : resident;
-        if (ctx->pxColdWaves < waves) { /* kernels in flight use the old block: it is freed stream-ordered, not now */
-            HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
-            hipFree(ctx->dPxCold); ctx->dPxCold = nullptr; ctx->pxColdWaves = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->dPxCold, (size_t)2 * waves * RT_COLD_STRIDE_BYTES));
-            ctx->pxColdWaves = waves;
-        }
-#ifdef RT_WG_EXPERIMENT
-        if (wgActive && ctx->wgUnits < waves) {
-            HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
-            hipFree(ctx->dWgRecords); ctx->dWgRecords = nullptr; ctx->wgUnits = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->dWgRecords, (size_t)2 * waves * RT_WG_GLOBAL_DWORDS * sizeof(uint32_t)));
-            ctx->wgUnits = waves;
-        }
-#endif
-#ifdef RT_QUEUED_EXPERIMENT
-        if (queued && ctx->qWaves < waves) {
-            HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
-            hipFree(ctx->dQRecords); ctx->dQRecords = nullptr; ctx->qWaves = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->dQRecords, (size_t)2 * waves * RT_Q_WAVE_DWORDS * sizeof(uint32_t)));
-            ctx->qWaves = waves;
-        }
-#endif
+    plan.resident = (long long)ctx->occPerCU[plan.variant] * ctx->numCUs;
+    return RT_OK;
+}
+
+/* ---- prepare buffers: the resident waves' pixel records */
+static int prepare_records(RtContext* ctx, const LaunchPlan& plan)
+{
+    const long long waves = ctx->gridOverride > plan.resident ? ctx->gridOverride : plan.resident;
+    if (ctx->pxColdWaves < waves) { /* kernels in flight use the old block: freed after a synchronise, not now */
+        HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
+        hipFree(ctx->dPxCold); ctx->dPxCold = nullptr; ctx->pxColdWaves = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->dPxCold, (size_t)2 * waves * RT_COLD_STRIDE_BYTES));
+        ctx->pxColdWaves = waves;
     }
-    /* Fused launches alternate between the context's two streams (own streams only), each with its own staging slab: the
-     * trace kernel of launch k+1 — other frames, nothing shared but the scene — starts while launch k drains (a launch ends
-     * with waves retiring one by one for as long as one pixel chain lasts), and only the rt_accumulate_kernels, which add
-     * into the accumulation buffer in FRAME order, are chained by events. */
-    const bool staged = nFrames > 1;
-    const size_t nPix = (size_t)ctx->localRows * ctx->W;
-    const bool twoOwn = ctx->twoStreams && ctx->stream == ctx->ownStream && ctx->sideStream;
-    const int lane = (staged && twoOwn && ctx->alternate) ? ctx->stagedNext : 0;
-    hipStream_t laneStream = lane ? ctx->sideStream : ctx->stream;
-    /* longest-chain-first queue order, learnt from the frames already rendered at this size */
-    if (ctx->lptEnabled && ctx->orderTiles != tiles) {
+    return exp_prepare(ctx, exp_of(ctx), waves);
+}
+
+/* ---- prepare buffers: longest-chain-first queue order, learnt from the frames already rendered at this size.  Re-sorted once 1, 2, 4, 8,
+ * ... frames have been recorded; the sort runs on the stream of the launch that first uses it, writes the order buffer that no running
+ * kernel reads, works on its own snapshot of the costs (running kernels keep raising them) — it never joins the two streams (a join in the
+ * middle of back-to-back launches serialises the next launch behind the drain of the previous one; round 4). */
+static int prepare_tile_order(RtContext* ctx, KArgs& a, int tiles, int nFrames, int lane, bool twoOwn)
+{
+    if (!ctx->lptEnabled) return RT_OK;
+    if (ctx->orderTiles != tiles) {
         HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
         hipFree(ctx->dTileCost); ctx->dTileCost = nullptr;
         hipFree(ctx->dTileOrder[0]); hipFree(ctx->dTileOrder[1]); ctx->dTileOrder[0] = ctx->dTileOrder[1] = nullptr;
@@ -1596,111 +1673,76 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         ctx->orderTiles = tiles;
         ctx->orderValid = false;
         ctx->orderCur = 0;
-        ctx->sortPending[0] = ctx->sortPending[1] = false;
-        ctx->retireValid[0] = ctx->retireValid[1] = false;
+        LaunchOrder::forget_order(ctx);
         ctx->framesSinceResize = 0;
         ctx->nextSortAt = 1;
     }
-    if (ctx->lptEnabled) {
-        const long long f = ctx->framesSinceResize;
-        /* Re-sort once 1, 2, 4, 8, ... frames have been recorded.  Round 4: the sort no longer joins the two streams (a join in the
-         * middle of back-to-back launches serialises the next launch behind the drain of the previous one: the driver's K = 20 run,
-         * 1 + 16 + 3 frames with the sort due at the 3-frame tail).  It runs on the stream of the launch that first uses it, writes
-         * the order buffer that no running kernel reads, works on its own snapshot of the costs (running kernels keep raising them),
-         * and the other stream is ordered after it by an event before its next launch. */
-        if (f >= ctx->nextSortAt) {
-            while (ctx->nextSortAt <= f) ctx->nextSortAt *= 2;
-            const int target = ctx->orderValid ? 1 - ctx->orderCur : 0;
-            const int ss = lane; /* a single frame's two halves: sorted on the main stream, the side stream waits */
-            hipStream_t S = ss ? ctx->sideStream : ctx->stream;
-            if (ss == 1 && ctx->needFork) {
-                HIP_TRY(ctx, hipEventRecord(ctx->evFork, ctx->stream));
-                HIP_TRY(ctx, hipStreamWaitEvent(ctx->sideStream, ctx->evFork, 0));
-                ctx->needFork = false;
-            }
-            if (ctx->retireValid[target]) HIP_TRY(ctx, hipStreamWaitEvent(S, ctx->evOrderRetire[target], 0)); /* its last readers on the other stream */
-            hipLaunchKernelGGL(rtk::rt_order_kernel, dim3(1), dim3(1024), 0, S, ctx->dTileCost, ctx->dTileKey, ctx->dTileOrder[target], tiles);
-            HIP_TRY(ctx, hipGetLastError());
-            HIP_TRY(ctx, hipEventRecord(ctx->evSort, S));
-            ctx->sortPending[ss] = false;
-            ctx->sortPending[1 - ss] = twoOwn;
-            if (ctx->orderValid && twoOwn) { /* the buffer going out of use: whatever the other stream holds so far may still read it */
-                HIP_TRY(ctx, hipEventRecord(ctx->evOrderRetire[ctx->orderCur], ss ? ctx->stream : ctx->sideStream));
-                ctx->retireValid[ctx->orderCur] = true;
-            }
-            if (ss == 1) ctx->sideDirty = true;
-            ctx->orderCur = target;
-            ctx->orderValid = true;
-            /* a new order moves pixels between the two halves of a two-part frame: the next such frame's halves must come after
-             * BOTH streams' last kernels that add into the accumulation buffer */
-            ctx->accWriterFull[0] = ctx->accWriterFull[1] = true;
-        }
-        a.tileCost = ctx->dTileCost;
-        a.tileOrder = ctx->orderValid ? ctx->dTileOrder[ctx->orderCur] : nullptr;
-        ctx->framesSinceResize += nFrames;
+    if (ctx->framesSinceResize >= ctx->nextSortAt) {
+        while (ctx->nextSortAt <= ctx->framesSinceResize) ctx->nextSortAt *= 2;
+        const int target = ctx->orderValid ? 1 - ctx->orderCur : 0;
+        const int ss = lane; /* a single frame's two halves: sorted on the main stream, the side stream waits */
+        int rc = LaunchOrder::begin_sort(ctx, ss, target);
+        if (rc) return rc;
+        hipLaunchKernelGGL(rtk::rt_order_kernel, dim3(1), dim3(1024), 0, LaunchOrder::stream_of(ctx, ss), ctx->dTileCost, ctx->dTileKey, ctx->dTileOrder[target], tiles);
+        HIP_TRY(ctx, hipGetLastError());
+        if ((rc = LaunchOrder::end_sort(ctx, ss, twoOwn, ctx->orderValid ? ctx->orderCur : -1))) return rc;
+        ctx->orderCur = target;
+        ctx->orderValid = true;
     }
-    /* Persistent launches.  Queue position q of part p is entry q*parts + p of the (longest chain
-     * first) tile order, so the parts are disjoint and equally heavy.  Each kernel is given as
-     * many single-wave workgroups as the chip keeps resident (occupancy query x CUs), never more
-     * than it has tiles: its first `grid` positions are taken by blockIdx, the rest through the
-     * part's atomic queue, which counts monotonically across launches (this launch's positions
-     * start at tileQueueBase).
-     * Two parts on two streams while the context runs on its own stream: a kernel ends with a
-     * drain phase as long as one pixel's serial chain, during which waves retire one by one;
-     * the other stream's kernel — different pixels, no dependence — picks up every slot that
-     * frees, and the two streams settle into taking turns.  With a caller-provided stream the
-     * caller's stream order is the contract, so there is one kernel on that stream. */
-    /* several frames in one launch: (tile, frame) items, per-frame colours staged and summed in frame order afterwards */
-    if (staged) {
-        const size_t need = (size_t)nFrames * nPix * 16;
-        if (!ctx->stagingUnavailable && ctx->stagingBytes[lane] < need) {
-            HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
-            /* both slabs are made by the first fused launch (a warm-up launch then pays for both: an allocation of this size
-             * takes milliseconds); grow once to the largest batch; if memory is short, to this batch */
-            for (int sl = 0; sl < (twoOwn && ctx->alternate ? 2 : 1); sl++) {
-                const int b = sl == 0 ? lane : 1 - lane;
-                if (ctx->stagingBytes[b] >= need) continue;
-                hipFree(ctx->dStaging[b]);
+    a.tileCost = ctx->dTileCost;
+    a.tileOrder = ctx->orderValid ? ctx->dTileOrder[ctx->orderCur] : nullptr;
+    ctx->framesSinceResize += nFrames;
+    return RT_OK;
+}
+
+/* ---- prepare buffers: the staging slab of a fused launch ([frame][pixel] colours awaiting rt_accumulate_kernel), one per stream so that
+ * consecutive fused launches can alternate between the streams.  Returns 1 when the launch cannot be staged on this lane (the caller
+ * falls back), 0 when a.staging is set. */
+static int prepare_staging(RtContext* ctx, KArgs& a, int nFrames, size_t nPix, int lane, bool twoOwn, bool* unavailable)
+{
+    *unavailable = false;
+    const size_t need = (size_t)nFrames * nPix * 16;
+    if (!ctx->stagingUnavailable && ctx->stagingBytes[lane] < need) {
+        HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
+        /* both slabs are made by the first fused launch (a warm-up launch then pays for both: an allocation of this size takes
+         * milliseconds); sized for the largest batch this context forms; if memory is short, for this batch */
+        for (int sl = 0; sl < (twoOwn && ctx->alternate ? 2 : 1); sl++) {
+            const int b = sl == 0 ? lane : 1 - lane;
+            if (ctx->stagingBytes[b] >= need) continue;
+            hipFree(ctx->dStaging[b]);
+            ctx->dStaging[b] = nullptr;
+            ctx->stagingBytes[b] = 0;
+            /* RT_FUSE_MAX frames when that is small (a partition of the image), the present cap otherwise (re-made if the cap grows) */
+            size_t capFrames = (size_t)(ctx->fuseCap > nFrames ? ctx->fuseCap : nFrames);
+            if ((size_t)RT_FUSE_MAX * nPix * 16 <= ((size_t)768 << 20)) capFrames = RT_FUSE_MAX;
+            const size_t cap = capFrames * nPix * 16;
+            size_t got = cap;
+            if (hipMalloc(&ctx->dStaging[b], cap) != hipSuccess) {
+                (void)hipGetLastError();
                 ctx->dStaging[b] = nullptr;
-                ctx->stagingBytes[b] = 0;
-                const size_t cap = (size_t)RT_MAX_FUSED_FRAMES * nPix * 16;
-                size_t got = cap;
-                if (hipMalloc(&ctx->dStaging[b], cap) != hipSuccess) {
+                got = need;
+                if (hipMalloc(&ctx->dStaging[b], need) != hipSuccess) {
                     (void)hipGetLastError();
                     ctx->dStaging[b] = nullptr;
-                    got = need;
-                    if (hipMalloc(&ctx->dStaging[b], need) != hipSuccess) {
-                        (void)hipGetLastError();
-                        ctx->dStaging[b] = nullptr;
-                        got = 0;
-                    }
+                    got = 0;
                 }
-                ctx->stagingBytes[b] = got;
-                if (got < need && b != lane) ctx->alternate = false; /* no room for the second slab: fused launches stay on one stream */
             }
+            ctx->stagingBytes[b] = got;
+            if (got < need && b != lane) ctx->alternate = false; /* no room for the second slab: fused launches stay on one stream (until rt_resize) */
         }
-        if (ctx->stagingUnavailable || ctx->stagingBytes[lane] < need) {
-            if (ctx->lptEnabled) ctx->framesSinceResize -= nFrames; /* counted again by the launches below */
-            if (lane == 1) { /* no room for the second slab: every fused launch on the main stream from now on */
-                ctx->alternate = false;
-                ctx->stagedNext = 0;
-                return launch_frames(ctx, frame0, nFrames);
-            }
-            /* not even one slab: the frames go out one launch each (a single-frame launch needs no staging) — a render
-             * call never fails for want of scratch — and the allocation is not tried again until the image is resized
-             * (every fused launch repeated two failing hipMallocs and a stream synchronise) */
-            ctx->stagingUnavailable = true;
-            for (int f = 0; f < nFrames; f++) {
-                const int rc1 = launch_frames(ctx, frame0 + f, 1); /* each counts itself in ctx->lastLaunched: a failure in the
-                                                                     * middle leaves the frame counter on the first frame not rendered */
-                if (rc1 != RT_OK) return rc1;
-            }
-            return RT_OK;
-        }
-        a.staging = ctx->dStaging[lane];
-        a.stagingStride = (uint32_t)nPix;
     }
-    /* launch tuner: collect finished probes, pick this launch's threshold */
+    if (ctx->stagingUnavailable || ctx->stagingBytes[lane] < need) {
+        *unavailable = true;
+        return RT_OK;
+    }
+    a.staging = ctx->dStaging[lane];
+    a.stagingStride = (uint32_t)nPix;
+    return RT_OK;
+}
+
+/* ---- launch tuner (suspension threshold 3/8 or 4/8) and the frames-per-launch budget: collect what has passed, decide for this launch */
+static RtContext::Tuner::Probe* tune_launch(RtContext* ctx, KArgs& a, bool staged, int nFrames)
+{
     RtContext::Tuner& tn = ctx->tuner;
     RtContext::Tuner::Probe* probe = nullptr;
     a.suspendNum = tn.decided;
@@ -1731,154 +1773,171 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
             }
         }
     }
-    const int parts = (!staged && twoOwn && tiles >= 2 && !wgActive) ? 2 : 1;
-    if ((parts == 2 || lane == 1) && ctx->needFork) { /* the side stream follows what the main stream holds so far */
-        HIP_TRY(ctx, hipEventRecord(ctx->evFork, ctx->stream));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->sideStream, ctx->evFork, 0));
-        ctx->needFork = false;
+    /* frames per fused launch (RT_FUSE_MIN ...): the cap the NEXT batches are cut to */
+    if (!ctx->fuseCapPinned)
+        for (auto& fp : ctx->fuseProbe) {
+            if (!fp.live || hipEventQuery(fp.stop) != hipSuccess) continue;
+            fp.live = false;
+            if (fp.prev < 0 || fp.frames <= 0) continue;
+            float ms = 0;
+            /* (a slot re-recorded by a later launch gives a negative or failing difference: skipped) */
+            if (hipEventElapsedTime(&ms, ctx->fuseProbe[fp.prev].stop, fp.stop) != hipSuccess || !(ms > 0)) { (void)hipGetLastError(); continue; }
+            const double perFrame = (double)ms / fp.frames;
+            int cap = (int)ceil(RT_FUSE_TARGET_MS / perFrame);
+            cap = cap < RT_FUSE_MIN ? RT_FUSE_MIN : cap > RT_FUSE_MAX ? RT_FUSE_MAX : cap;
+            if (cap != ctx->fuseCap && ctx->verbose) fprintf(stderr, "[raytrace_hip] fused launches: %.3f ms per frame -> up to %d frames per launch\n", perFrame, cap);
+            ctx->fuseCap = cap;
+        }
+    return probe;
+}
+static void mark_fused_launch_end(RtContext* ctx, hipStream_t st, int nFrames)
+{
+    if (ctx->fuseCapPinned) return;
+    int slot = -1;
+    for (int i = 0; i < (int)(sizeof(ctx->fuseProbe) / sizeof(ctx->fuseProbe[0])); i++)
+        if (!ctx->fuseProbe[i].live && i != ctx->fuseLast) { slot = i; break; }
+    if (slot < 0) { ctx->fuseLast = -1; return; } /* all in flight: the chain of stop events breaks here */
+    RtContext::FuseProbe& fp = ctx->fuseProbe[slot];
+    if (!fp.stop) hipEventCreate(&fp.stop);
+    if (fp.stop && hipEventRecord(fp.stop, st) == hipSuccess) {
+        fp.frames = nFrames;
+        fp.prev = ctx->fuseLast; /* its event stays recorded (a slot is reused only when it is not the last one) */
+        fp.live = true;
+        ctx->fuseLast = slot;
     }
-    /* a kernel that adds into the accumulation buffer (a single-frame trace kernel; the accumulate kernel of a fused
-     * launch) comes after the last such kernel on the OTHER stream; its own stream orders it after its predecessors */
-    /* (the halves of consecutive two-part frames need no such wait: between two sorts of the tile order a stream's half is the
-     * same set of pixels, and a sort joins the streams) */
-    auto order_acc_writer = [&](int s, bool full) -> int {
-        hipStream_t st = s ? ctx->sideStream : ctx->stream;
-        if (ctx->accFullPending[1 - s]) { /* the other stream's last whole-image writer: once waited for, everything later on this stream follows it */
-            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->evAccFull[1 - s], 0));
-            ctx->accFullPending[1 - s] = false;
-        }
-        if (ctx->accWriterPending[1 - s] && (full || ctx->accWriterFull[1 - s])) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->evAccWriter[1 - s], 0));
-        return RT_OK;
-    };
-    auto mark_acc_writer = [&](int s, bool full) -> int {
-        HIP_TRY(ctx, hipEventRecord(ctx->evAccWriter[s], s ? ctx->sideStream : ctx->stream));
-        ctx->accWriterPending[s] = true;
-        ctx->accWriterFull[s] = full;
-        if (full) {
-            HIP_TRY(ctx, hipEventRecord(ctx->evAccFull[s], s ? ctx->sideStream : ctx->stream));
-            ctx->accFullPending[s] = true;
-        }
-        return RT_OK;
-    };
+}
+
+/* ---- enqueue: the trace kernel(s) of one launch.
+ * Persistent launches.  Queue position q of part p is entry q*parts + p of the (longest chain first) tile order, so the parts are
+ * disjoint and equally heavy.  Each kernel is given as many single-wave workgroups as the chip keeps resident, never more than it has
+ * work items: its first `grid` positions are taken by blockIdx, the rest through the part's atomic queue, which counts monotonically
+ * across launches (this launch's positions start at tileQueueBase).
+ * Two parts on two streams for a single frame while the context runs on its own stream: a kernel ends with a drain phase as long as one
+ * pixel's serial chain, during which waves retire one by one; the other stream's kernel — different pixels, no dependence — picks up
+ * every slot that frees.  With a caller-provided stream the caller's stream order is the contract: one kernel on that stream. */
+static int enqueue_trace(RtContext* ctx, KArgs& a, const LaunchPlan& plan, int tiles, int nFrames, int lane, int parts, RtContext::Tuner::Probe* probe)
+{
+    const bool staged = nFrames > 1;
     for (int p = 0; p < parts; p++) {
         const int partTiles = (tiles - p + parts - 1) / parts;
-        /* frames per item: 1 = the most items and the shortest tail.  The FLAT scenes' per-frame chains are short and
-         * uniform; there one pixel set-up per group of frames is worth 7 % (config 2: 0.765 -> 0.710 ms/frame at groups
-         * of 4) as long as every resident wave still gets >= 8 items; fewer items than that, or groups of 8+, lose it to the
-         * tail again, and the BVH scenes gain nothing measurable (profiles/r02_frame_group_sweep.txt). */
+        /* frames per item: 1 = the most items and the shortest tail.  The FLAT scenes' per-frame chains are short and uniform; there one
+         * pixel set-up per group of frames is worth 7 % (config 2: 0.765 -> 0.710 ms/frame at groups of 4) as long as every resident wave
+         * still gets >= 8 items; fewer items than that, or groups of 8+, lose it to the tail again, and the BVH scenes gain nothing
+         * measurable (profiles/r02_frame_group_sweep.txt; their kernel variants are compiled without groups). */
         int group = 1;
-        if (staged && ctx->flatScene && ctx->params.numRaysPerPixel < 65536) { /* the BVH kernel variants are compiled without groups */
+        if (staged && ctx->flatScene && ctx->params.numRaysPerPixel < 65536) {
             if (ctx->frameGroupOverride > 0) group = ctx->frameGroupOverride;
             else
-                while (group < 4 && 2 * group <= nFrames
-                       && (long long)partTiles * ((nFrames + 2 * group - 1) / (2 * group)) >= 8 * resident) group *= 2;
+                while (group < 4 && 2 * group <= nFrames && (long long)partTiles * ((nFrames + 2 * group - 1) / (2 * group)) >= 8 * plan.resident) group *= 2;
             if (group > nFrames) group = nFrames;
         }
         a.frameGroup = group;
         a.frameGroups = staged ? (nFrames + group - 1) / group : 1;
         const long long items = (long long)partTiles * a.frameGroups;
-        int grid = (int)(resident < items ? resident : items);
+        int grid = (int)(plan.resident < items ? plan.resident : items);
         if (ctx->gridOverride > 0) grid = (int)(ctx->gridOverride < items ? ctx->gridOverride : items);
         a.launchTiles = partTiles;
         a.launchItems = (int)items;
         a.orderOffset = p;
         a.orderStride = parts;
-        /* One kernel alone: all its workgroups become resident at once, the first `grid` positions go
-         * by blockIdx and only the rest through the queue.  Two kernels sharing the chip: workgroups
-         * are dispatched as slots free up, possibly late, so every position — the longest chains
-         * first — comes from the queue. */
+        /* One kernel alone: all its workgroups become resident at once, the first `grid` positions go by blockIdx and only the rest
+         * through the queue.  Two kernels sharing the chip: workgroups are dispatched as slots free up, possibly late, so every
+         * position — the longest chains first — comes from the queue. */
         a.queueStart = parts == 2 ? 1 : 0;
-        if (ctx->verbose) fprintf(stderr, "[raytrace_hip] launch variant=%d part=%d/%d tiles=%d grid=%d perCU=%d lds=%zu\n", variant, p, parts, partTiles, grid, ctx->occPerCU[variant], stackBytes);
+        if (ctx->verbose) fprintf(stderr, "[raytrace_hip] launch variant=%d part=%d/%d tiles=%d grid=%d perCU=%d lds=%zu\n", plan.variant, p, parts, partTiles, grid, ctx->occPerCU[plan.variant], plan.ldsBytes);
         /* stream, pixel-record slot and tile-queue counter of this kernel: part p of a two-part frame, or the fused launch's lane */
         const int q = parts == 2 ? p : lane;
-        hipStream_t st = q ? ctx->sideStream : ctx->stream;
+        hipStream_t st = LaunchOrder::stream_of(ctx, q);
         a.pxCold = (float4*)((char*)ctx->dPxCold + (size_t)q * ctx->pxColdWaves * RT_COLD_STRIDE_BYTES);
-#ifdef RT_QUEUED_EXPERIMENT
-        a.qRecords = queued ? (uint32_t*)ctx->dQRecords + (size_t)q * ctx->qWaves * RT_Q_WAVE_DWORDS : nullptr;
-#endif
         a.tileQueue = ctx->dTileQueue + q;
         a.tileQueueBase = ctx->tileQueueNext[q] - (a.queueStart ? 0ull : (unsigned long long)grid);
-#ifdef RT_XCD_EXPERIMENT
-        const bool xcdQ = ctx->xcdAffinity > 0 && staged && !wgActive && !queued;
-#else
-        const bool xcdQ = false;
-#endif
-        if (xcdQ) {
-            if (!ctx->dXcdQueues) HIP_TRY(ctx, hipMalloc(&ctx->dXcdQueues, 16 * sizeof(unsigned long long)));
-            if (ctx->xcdAffinity == 2) {
-                if (ctx->blockOrderTiles != tiles) { /* position -> tile: eight blocks (4 across, 2 down), rows within a block */
-                    std::vector<uint32_t> order;
-                    order.reserve(tiles);
-                    for (int by = 0; by < 2; by++)
-                        for (int bx = 0; bx < 4; bx++) {
-                            const int x0 = a.tilesX * bx / 4, x1 = a.tilesX * (bx + 1) / 4, y0 = a.tilesY * by / 2, y1 = a.tilesY * (by + 1) / 2;
-                            for (int y = y0; y < y1; y++)
-                                for (int x = x0; x < x1; x++) order.push_back((uint32_t)(y * a.tilesX + x));
-                        }
-                    HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
-                    hipFree(ctx->dBlockOrder); ctx->dBlockOrder = nullptr;
-                    HIP_TRY(ctx, hipMalloc(&ctx->dBlockOrder, sizeof(uint32_t) * tiles));
-                    HIP_TRY(ctx, hipMemcpy(ctx->dBlockOrder, order.data(), sizeof(uint32_t) * tiles, hipMemcpyHostToDevice));
-                    ctx->blockOrderTiles = tiles;
-                }
-                a.tileOrder = ctx->dBlockOrder;
-            }
-            a.xcdQueues = ctx->dXcdQueues + 8 * q;
-            a.queueStart = 1;
-            HIP_TRY(ctx, hipMemsetAsync(a.xcdQueues, 0, 8 * sizeof(unsigned long long), st));
-        }
-        if (ctx->sortPending[q]) { /* the order array this kernel reads was sorted on the other stream */
-            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->evSort, 0));
-            ctx->sortPending[q] = false;
-        }
-        if (!staged) { /* the trace kernel itself adds into the accumulation buffer (RCC:20-23) */
-            const int orc = order_acc_writer(q, parts == 1);
-            if (orc) return orc;
-        }
-#ifdef RT_WG_EXPERIMENT
-        if (wgActive) { /* its own tile counter from zero (the number of overshooting fetches of a workgroup launch is not fixed) */
-            a.qRecords = (uint32_t*)ctx->dWgRecords + (size_t)q * ctx->wgUnits * RT_WG_GLOBAL_DWORDS;
-            HIP_TRY(ctx, hipMemsetAsync(ctx->dTileQueue + q, 0, sizeof(unsigned long long), st));
-            a.tileQueueBase = 0ull;
-        }
-#endif
+        int rc;
+        if ((rc = LaunchOrder::before_order_read(ctx, q))) return rc;
+        if (!staged && (rc = LaunchOrder::before_acc_write(ctx, q, parts == 1))) return rc; /* the trace kernel itself adds into the accumulation buffer (RCC:20-23) */
+        bool ownQueue = false;
+        if ((rc = exp_pre_launch(ctx, exp_of(ctx), a, q, st, staged, tiles, &ownQueue))) return rc;
         if (probe) hipEventRecord(probe->start, st);
-        hipLaunchKernelGGL(parts == 2 ? kernHalf : kern, dim3(grid), dim3(blockThreads), ldsBytes, st, a);
-#ifdef RT_WG_EXPERIMENT
-        if (wgActive) {
-            HIP_TRY(ctx, hipMemsetAsync(ctx->dTileQueue + q, 0, sizeof(unsigned long long), st));
-            ctx->tileQueueNext[q] = 0ull - ((unsigned long long)items + (a.queueStart ? (unsigned long long)grid : 0ull)); /* + the bookkeeping below = 0 */
-        }
-#endif
+        hipLaunchKernelGGL(parts == 2 ? plan.kernHalf : plan.kern, dim3(grid), dim3(plan.blockThreads), plan.ldsBytes, st, a);
         if (probe) { hipEventRecord(probe->stop, st); probe->live = true; }
         HIP_TRY(ctx, hipGetLastError()); /* a refused launch ran no wave: the device counter did not move */
+        if (staged) mark_fused_launch_end(ctx, st, nFrames);
+        if ((rc = exp_post_launch(ctx, exp_of(ctx), q, st))) return rc;
         /* every tile not taken by blockIdx is one successful fetch, and each of the grid waves overshoots once */
-        if (!xcdQ) ctx->tileQueueNext[q] += (unsigned long long)items + (a.queueStart ? (unsigned long long)grid : 0ull);
-        if (q == 1) ctx->sideDirty = true;
-        if (!staged) {
-            const int mrc = mark_acc_writer(q, parts == 1);
-            if (mrc) return mrc;
+        if (!ownQueue) ctx->tileQueueNext[q] += (unsigned long long)items + (a.queueStart ? (unsigned long long)grid : 0ull);
+        if (q == 1) LaunchOrder::side_used(ctx);
+        if (!staged && (rc = LaunchOrder::after_acc_write(ctx, q, parts == 1))) return rc;
+    }
+    if (!staged && parts == 1) LaunchOrder::other_stream_settled(ctx, 0); /* ordered before the main stream's kernel just launched */
+    return RT_OK;
+}
+
+/* ---- enqueue: RCC:18-23 for a fused launch's frames, in frame order, after every earlier frame's */
+static int enqueue_accumulate(RtContext* ctx, const KArgs& a, int nFrames, size_t nPix, int lane)
+{
+    int blocks = (int)((nPix + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    int rc = LaunchOrder::before_acc_write(ctx, lane, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rtk::rt_accumulate_kernel, dim3(blocks), dim3(256), 0, LaunchOrder::stream_of(ctx, lane), (const float4*)ctx->dStaging[lane], nFrames, nPix,
+                       (float4*)a.accumulated, (float4*)a.frameRender, nPix);
+    HIP_TRY(ctx, hipGetLastError());
+    if ((rc = LaunchOrder::after_acc_write(ctx, lane, true))) return rc;
+    LaunchOrder::other_stream_settled(ctx, lane); /* this accumulate is ordered after it; later writers wait for this one */
+    return RT_OK;
+}
+
+static int launch_frames(RtContext* ctx, int frame0, int nFrames)
+{
+    KArgs a;
+    fill_args(ctx, frame0, nFrames, a);
+    const int tiles = a.tilesX * a.tilesY;
+    if (tiles == 0) return RT_OK;
+    LaunchPlan plan;
+    bool many = false;
+    int rc = choose_variant(ctx, a, plan, &many);
+    if (rc) return rc;
+    if ((rc = prepare_records(ctx, plan))) return rc;
+    /* Fused launches (several frames: (tile, frame) items, per-frame colours staged and summed in frame order afterwards) alternate
+     * between the context's two streams (own streams only), each with its own staging slab: the trace kernel of launch k+1 — other
+     * frames, nothing shared but the scene — starts while launch k drains, and only the rt_accumulate_kernels, which add into the
+     * accumulation buffer in FRAME order, are chained by events. */
+    const bool staged = nFrames > 1;
+    const size_t nPix = (size_t)ctx->localRows * ctx->W;
+    const bool twoOwn = ctx->twoStreams && ctx->stream == ctx->ownStream && ctx->sideStream;
+    const int lane = (staged && twoOwn && ctx->alternate) ? ctx->stagedNext : 0;
+    if ((rc = prepare_tile_order(ctx, a, tiles, nFrames, lane, twoOwn))) return rc;
+    if (staged) {
+        bool unavailable = false;
+        if ((rc = prepare_staging(ctx, a, nFrames, nPix, lane, twoOwn, &unavailable))) return rc;
+        if (unavailable) {
+            if (ctx->lptEnabled) ctx->framesSinceResize -= nFrames; /* counted again by the launches below */
+            if (lane == 1) { /* no room for the second slab: every fused launch on the main stream from now on */
+                ctx->alternate = false;
+                ctx->stagedNext = 0;
+                return launch_frames(ctx, frame0, nFrames);
+            }
+            /* not even one slab: the frames go out one launch each (a single-frame launch needs no staging) — a render call never
+             * fails for want of scratch — and the allocation is not tried again until the image is resized */
+            ctx->stagingUnavailable = true;
+            for (int f = 0; f < nFrames; f++)
+                if ((rc = launch_frames(ctx, frame0 + f, 1))) return rc; /* each counts itself in ctx->lastLaunched */
+            return RT_OK;
         }
     }
-    if (!staged && parts == 1) ctx->accWriterPending[1] = false; /* ordered before the main stream's kernel just launched */
+    RtContext::Tuner::Probe* probe = tune_launch(ctx, a, staged, nFrames);
+    const int parts = (!staged && twoOwn && tiles >= 2 && plan.twoPartsAllowed) ? 2 : 1;
+    if ((parts == 2 || lane == 1) && (rc = LaunchOrder::fork_side(ctx))) return rc; /* the side stream follows what the main stream holds so far */
+    if ((rc = enqueue_trace(ctx, a, plan, tiles, nFrames, lane, parts, probe))) return rc;
     if (staged) {
-        int blocks = (int)((nPix + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        /* RCC:18-23 for this launch's frames, after every earlier frame's: the other stream's last writer is waited for */
-        const int orc = order_acc_writer(lane, true);
-        if (orc) return orc;
-        hipLaunchKernelGGL(rtk::rt_accumulate_kernel, dim3(blocks), dim3(256), 0, laneStream, (const float4*)ctx->dStaging[lane], nFrames, nPix, (float4*)a.accumulated,
-                           (float4*)a.frameRender, nPix);
-        HIP_TRY(ctx, hipGetLastError());
-        const int mrc = mark_acc_writer(lane, true);
-        if (mrc) return mrc;
-        ctx->accWriterPending[1 - lane] = false; /* this accumulate is ordered after it; later writers wait for this one */
+        if ((rc = enqueue_accumulate(ctx, a, nFrames, nPix, lane))) return rc;
         if (twoOwn && ctx->alternate) ctx->stagedNext = 1 - lane;
     }
     ctx->pixelFrames += (uint64_t)ctx->localRows * ctx->W * nFrames;
     ctx->lastLaunched += nFrames;
     return RT_OK;
 }
+
+extern "C" {
 
 static int check_renderable(RtContext* ctx)
 {
@@ -1893,7 +1952,7 @@ static int check_renderable(RtContext* ctx)
 static bool gpu_idle(RtContext* ctx)
 {
     if (hipStreamQuery(ctx->stream) != hipSuccess) return false;
-    if (ctx->sideStream && ctx->sideDirty && hipStreamQuery(ctx->sideStream) != hipSuccess) return false;
+    if (ctx->sideStream && ctx->ord.sideDirty && hipStreamQuery(ctx->sideStream) != hipSuccess) return false;
     return true;
 }
 
@@ -1904,7 +1963,7 @@ int rt_render_frame(RtContext* ctx)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     /* Frames requested while earlier ones still execute are held back and leave as one fused launch (each pixel
      * runs its frames back to back: same bits as one launch per frame, without a chip-wide drain per frame) when
-     * RT_MAX_FUSED_FRAMES have gathered or at the next call that needs them.  An idle GPU starts at once. */
+     * fuseCap have gathered or at the next call that needs them.  An idle GPU starts at once. */
     if (ctx->coalesce && ctx->fuseFrames && ctx->params.accumulate && ctx->stream == ctx->ownStream) {
         if (gpu_idle(ctx)) {
             RT_FLUSH(ctx);
@@ -1915,7 +1974,7 @@ int rt_render_frame(RtContext* ctx)
         }
         ctx->pending++;
         ctx->frame++; /* RCM:94 */
-        if (ctx->pending >= RT_MAX_FUSED_FRAMES) RT_FLUSH(ctx);
+        if (ctx->pending >= ctx->fuseCap) RT_FLUSH(ctx);
         return RT_OK;
     }
     RT_FLUSH(ctx);
@@ -1946,7 +2005,7 @@ int rt_render_frames(RtContext* ctx, int n)
          * chip-wide drain at the end of a launch is paid once per batch instead of once per
          * frame.  Batches are capped to keep launches short. */
         while (n > 0) {
-            const int k = n < RT_MAX_FUSED_FRAMES ? n : RT_MAX_FUSED_FRAMES;
+            const int k = n < ctx->fuseCap ? n : ctx->fuseCap;
             rc = launch_frames(ctx, ctx->frame, k);
             if (rc) return rc;
             ctx->frame += k;
@@ -2139,9 +2198,8 @@ int rt_get_counters(RtContext* ctx, RtCounters* out)
     out->modelVisits = sum[5];
     out->pixelFrames = ctx->pixelFrames;
     out->gpuMs = ctx->gpuMs;
-#ifdef RT_WG_EXPERIMENT
-    if (sum[7]) return fail(ctx, RT_ERR_HIP, "workgroup kernel: the watchdog fired in %llu waves (a wave waited too long for the others)", sum[7]);
-#endif
+    /* slot 7 = a kernel's watchdog (only the workgroup experiment's kernel has one; the product kernels never write it) */
+    if (sum[7]) return fail(ctx, RT_ERR_HIP, "a kernel's watchdog fired in %llu waves (a wave waited too long for the others)", sum[7]);
     return RT_OK;
 }
 
@@ -2182,6 +2240,8 @@ struct DevScratch {
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
     float* f() const { return (float*)p; }
 };
+
+int rt_debug_fused_frames_cap(const RtContext* ctx) { return ctx ? ctx->fuseCap : RT_ERR_INVALID_ARG; }
 
 int rt_debug_intersect(RtContext* ctx, const float* origins, const float* dirs, int n, float* out10)
 {

@@ -445,17 +445,23 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
         };
 #ifdef RT_NO_PACKED_FILTER /* A/B build (make EXTRA=-DRT_NO_PACKED_FILTER): one model per step */
         if (!MANY) {
-#else
-        if (!MANY && STATS) { /* up to 64 models: one lockstep loop, bit m = model m (with the audits) */
-#endif
             for (int m = 0; m < nf; m++) cand |= (test_model(m) ? 1ull : 0ull) << m;
-        } else if (!MANY) {
+        } else if (false) {
+#else
+        unsigned long long scalarCand = 0;
+        if (!MANY && STATS) { /* up to 64 models: the one-model-per-step loop for the exact counters and the audits ... */
+            for (int m = 0; m < nf; m++) scalarCand |= (test_model(m) ? 1ull : 0ull) << m;
+        }
+        if (!MANY) { /* ... and the packed loop that SHIPS decides the candidates in both builds (the stats build audits it too) */
+#endif
             /* The shipped form of the same loop, TWO models per step (round 4): the boxes sit in SGPRs, and a VALU instruction
              * with an SGPR source issues at the slow rate on gfx950 while v_pk_add/mul_f32 take an SGPR PAIR for the price of one
              * (the two-spheres-per-step pre-test above, profiles/r03_valu_op_rates.txt).  The pair records (rt_context.hip,
              * append_filter_pairs) hold the two models' boxes side by side — minx0 minx1 miny0 miny1 ... — so that one scalar load
              * fills the pairs and the twelve (b - o) and twelve (.) * (1 / d) of two slab tests are twelve packed instructions.
-             * Same operations on the same values per model: the candidate masks are those of the loop above. */
+             * Same operations on the same values per model; the masks are a SUPERSET of the one-model-per-step loop's (a NaN or an
+             * infinite tNear keeps the model here where box_dst's comparisons reject it: conservative) — the stats build counts any
+             * model that loop keeps and this one drops as a filter violation (must be 0). */
             typedef float rt_f2v __attribute__((ext_vector_type(2)));
             const rt_f2v px = {rpos.x, rpos.x}, py = {rpos.y, rpos.y}, pz = {rpos.z, rpos.z};
             const rt_f2v ix = {winv.x, winv.x}, iy = {winv.y, winv.y}, iz = {winv.z, winv.z};
@@ -485,6 +491,9 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
                 const bool keep1 = (m + 1 < nf) && keep_of(t0x.y, t1x.y, t0y.y, t1y.y, t0z.y, t1z.y, __float_as_uint(q[13]));
                 cand |= ((keep0 ? 1ull : 0ull) << m) | ((keep1 ? 1ull : 0ull) << (m + 1));
             }
+#ifndef RT_NO_PACKED_FILTER
+            if (STATS && (scalarCand & ~cand)) st.filterViolations += (uint32_t)__popcll(scalarCand & ~cand);
+#endif
         } else {
             /* more than 64 models: chunk boxes first (a chunk no lane of the wave hits costs one box test instead of
              * 16), candidates beyond model 62 go to the lane's LDS extension words */
@@ -639,17 +648,25 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
 #pragma clang loop unroll(disable)
             for (int burst = 0; burst < RT_INNER_BURST; burst++) {
                 const bool mine = t.cur < RT_CODE_DONE;
-                /* who works in which round is decided on scalar masks (no VALU): round j runs for the pairs whose lane j is at an inner node */
+                /* who works in which round is decided on scalar masks (no VALU): round j runs for the pairs whose lane j is at an inner
+                 * node.  Only lanes that are inside traverse() can help (the others are switched off in EXEC — a pixel without work, a
+                 * lane that is shading): a lane whose partner is absent fetches both halves itself (mLonely; rare: every lane with a
+                 * path re-enters the traversal in the iteration in which it got its ray). */
                 const unsigned long long mMine = __ballot(mine);
-                const unsigned long long mEven = mMine & 0x5555555555555555ull, mOdd = mMine & 0xAAAAAAAAAAAAAAAAull;
-                const unsigned long long mAct0 = mEven | (mEven << 1), mAct1 = mOdd | (mOdd >> 1);
-                const bool odd = __builtin_amdgcn_inverse_ballot_w64(0xAAAAAAAAAAAAAAAAull);
+                const unsigned long long mAlive = __ballot(true);
+                const unsigned long long EVEN = 0x5555555555555555ull, ODD = 0xAAAAAAAAAAAAAAAAull;
+                const unsigned long long mBoth = mAlive & (((mAlive & EVEN) << 1) | ((mAlive & ODD) >> 1)); /* lanes whose partner is here too */
+                const unsigned long long mPaired = mMine & mBoth, mLonely = mMine & ~mBoth;
+                const unsigned long long mAct0 = (mPaired & EVEN) | ((mPaired & EVEN) << 1), mAct1 = (mPaired & ODD) | ((mPaired & ODD) >> 1);
+                const bool odd = __builtin_amdgcn_inverse_ballot_w64(ODD);
                 /* quad_perm selectors: the pair's lane 0 / lane 1 / the partner */
                 constexpr int SEL0 = 0xA0 /* [0,0,2,2] */, SEL1 = 0xF5 /* [1,1,3,3] */, SELX = 0xB1 /* [1,0,3,2] */;
 #define RT_DPP_I(v, sel) __builtin_amdgcn_update_dpp(0, (int)(v), sel, 0xf, 0xf, true)
 #define RT_DPP_F(v, sel) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(v)), sel, 0xf, 0xf, true))
+                const uint32_t offMine = (uint32_t)(t.cur << 4);
+                float dstA = RT_INF, dstB = RT_INF;
+                uint32_t codeA = 0u, codeB = 0u;
                 if (__builtin_amdgcn_inverse_ballot_w64(mAct0 | mAct1)) {
-                    const uint32_t offMine = (uint32_t)(t.cur << 4);
                     const uint32_t halfOff = odd ? 32u : 0u;
                     float D0 = RT_INF, D1 = RT_INF;
                     uint32_t C0 = 0u, C1 = 0u;
@@ -693,25 +710,44 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
                     const uint32_t keepC = odd ? C1 : C0, giveC = odd ? C0 : C1;
                     const float gotD = RT_DPP_F(giveD, SELX);
                     const uint32_t gotC = (uint32_t)RT_DPP_I(giveC, SELX);
-                    if (mine) { /* ---- B: one inner node, RC:262-282 */
-                        if (STATS && !t.rootStep) st.inner++;
-                        t.rootStep = false;
-                        phase_mark<STATS>(st, PH_INNER);
-                        const float dstA = odd ? gotD : keepD, dstB = odd ? keepD : gotD;
-                        const uint32_t codeA = odd ? gotC : keepC, codeB = odd ? keepC : gotC;
-                        bool isNearestA = dstA <= dstB;
-                        float dstNear = isNearestA ? dstA : dstB;
-                        float dstFar = isNearestA ? dstB : dstA;
-                        uint32_t codeNear = isNearestA ? codeA : codeB;
-                        uint32_t codeFar = isNearestA ? codeB : codeA;
-                        if (dstNear < h.dst) {
-                            if (dstFar < h.dst) { stackBase[t.sp * RT_WAVE] = codeFar; t.sp++; }
-                            t.cur = codeNear;
-                        } else if (t.sp == 0) {
-                            t.cur = RT_CODE_NEXT_MODEL;
-                        } else {
-                            t.cur = stackBase[(--t.sp) * RT_WAVE];
+                    dstA = odd ? gotD : keepD;
+                    dstB = odd ? keepD : gotD;
+                    codeA = odd ? gotC : keepC;
+                    codeB = odd ? keepC : gotC;
+                }
+                if (mLonely) { /* wave-uniform and rare: no partner in the traversal, both halves by the lane itself */
+                    if (__builtin_amdgcn_inverse_ballot_w64(mLonely)) {
+                        const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pairs) + offMine);
+                        {
+                            const float4 lo = q[0], hi = q[1];
+                            const float bmin[3] = {lo.x, lo.y, lo.z}, bmax[3] = {hi.x, hi.y, hi.z};
+                            dstA = box_dst(t.lpos, t.linv, bmin, bmax);
+                            codeA = __float_as_uint(lo.w);
                         }
+                        {
+                            const float4 lo = q[2], hi = q[3];
+                            const float bmin[3] = {lo.x, lo.y, lo.z}, bmax[3] = {hi.x, hi.y, hi.z};
+                            dstB = box_dst(t.lpos, t.linv, bmin, bmax);
+                            codeB = __float_as_uint(lo.w);
+                        }
+                    }
+                }
+                if (mine) { /* ---- B: one inner node, RC:262-282 */
+                    if (STATS && !t.rootStep) st.inner++;
+                    t.rootStep = false;
+                    phase_mark<STATS>(st, PH_INNER);
+                    bool isNearestA = dstA <= dstB;
+                    float dstNear = isNearestA ? dstA : dstB;
+                    float dstFar = isNearestA ? dstB : dstA;
+                    uint32_t codeNear = isNearestA ? codeA : codeB;
+                    uint32_t codeFar = isNearestA ? codeB : codeA;
+                    if (dstNear < h.dst) {
+                        if (dstFar < h.dst) { stackBase[t.sp * RT_WAVE] = codeFar; t.sp++; }
+                        t.cur = codeNear;
+                    } else if (t.sp == 0) {
+                        t.cur = RT_CODE_NEXT_MODEL;
+                    } else {
+                        t.cur = stackBase[(--t.sp) * RT_WAVE];
                     }
                 }
 #undef RT_DPP_I

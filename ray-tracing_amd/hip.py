@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "rt_write_accumulated", "rt_timer_begin", "rt_timer_end",
     "rt_enable_stats", "rt_reset_counters", "rt_get_counters", "rt_build_bvh", "rt_build_bvh_mt", "rt_build_bvh_gpu", "rt_build_bvh_gpu_release", "rt_camera_view_params", "rt_version",
     "rt_debug_intersect", "rt_debug_math_eval", "rt_debug_phase_profile", "rt_build_bvh_gpu_batch",
-    "rt_flush", "rt_validate_scene", "rt_debug_layout", "rt_debug_layout_free",
+    "rt_flush", "rt_validate_scene", "rt_debug_layout", "rt_debug_layout_free", "rt_debug_fused_frames_cap",
     "rt_create_multi", "rt_destroy_multi", "rt_multi_count", "rt_multi_context", "rt_multi_resize", "rt_multi_upload_scene",
     "rt_multi_update_models", "rt_multi_update_spheres", "rt_multi_set_params", "rt_multi_reset_accumulation",
     "rt_multi_render_frame", "rt_multi_render_frames", "rt_multi_synchronize", "rt_gather_accumulated", "rt_gather_frame",
@@ -55,6 +55,7 @@ class HipApi(abi.CApi):
         "validate_scene": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
         "debug_layout": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p]),
         "debug_layout_free": (None, [C.c_void_p]),
+        "debug_fused_frames_cap": (C.c_int, [C.c_void_p]),
         "debug_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
         "debug_math_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
         "debug_phase_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -326,6 +327,9 @@ class HipTracer(abi.Tracer):
         """rt_gather_rccl: this rank's packed tile to `root` over the caller's ncclComm_t (RCCL), de-interleaved into the whole image
         at device_ptr on root (others pass None / 0)."""
         self._check(self.api.gather_rccl(self.h, nccl_comm, int(root), 1 if accumulated else 0, device_ptr, nbytes))
+
+    def fused_frames_cap(self):
+        return self.api.debug_fused_frames_cap(self.h)
 
     def synchronize(self):
         self._check(self.api.synchronize(self.h))

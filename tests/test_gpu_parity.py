@@ -817,3 +817,37 @@ def test_abi_errors(pkg, api):
     out = np.zeros((4, 4, 4), np.float32)
     assert api.read_accumulated(tr.h, out.ctypes.data, out.nbytes) == a.RT_ERR_INVALID_ARG
     tr.close()
+
+
+@pytest.mark.gpu
+def test_frames_per_fused_launch_follow_the_measured_frame_time(pkg, api, orc):
+    """Round 5: the number of frames in a fused launch is a budget (16 ... 64) set from the frame time measured on the previous launches:
+    a small image (short frames) is batched by up to 64, and whatever the batches were the accumulation equals the oracle's."""
+    w, h, frames = 72, 40, 150
+    tr = api.create_tracer(0)
+    mgr = pkg.scenes.get(2).make_manager(tr, api, w, h)
+    mgr.OnEnable(renderSeed=3)
+    assert tr.fused_frames_cap() == 16
+    for n in (40, 40, 40, 30):      # rt_render_frames cuts its batches to the cap of the moment
+        mgr.RenderFrames(n)
+        tr.synchronize()
+    assert 16 < tr.fused_frames_cap() <= 64, tr.fused_frames_cap()
+    got = tr.read_accumulated()
+    assert tr.frame() == 1 + frames
+    tr.resize(w, h)                  # a new geometry starts from the minimum again
+    assert tr.fused_frames_cap() == 16
+    tr.close()
+    ref = orc.create_tracer(min(32, os.cpu_count() or 8))
+    m2 = pkg.scenes.get(2).make_manager(ref, orc, w, h)
+    m2.OnEnable(renderSeed=3)
+    m2.RenderFrames(frames)
+    assert np.array_equal(got.view(np.uint32), ref.read_accumulated().view(np.uint32))
+    ref.close()
+
+
+@pytest.mark.gpu
+def test_pinned_frames_per_fused_launch(pkg, api, monkeypatch):
+    monkeypatch.setenv("RT_FUSE_CAP", "5")
+    tr = api.create_tracer(0)
+    assert tr.fused_frames_cap() == 5
+    tr.close()
