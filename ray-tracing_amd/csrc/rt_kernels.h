@@ -579,6 +579,9 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
      * of the lanes that entered are still traversing. */
     bool atNext, atLeaf, atInner;
     int nA, nB, nC;
+#ifdef RT_TRAV_WATCHDOG
+    uint32_t watchdog = 0;
+#endif
 #define RT_TRAV_VOTE()                                                                                         \
     do {                                                                                                       \
         /* a lane between models that has no model left is done: no more demand for phase A */              \
@@ -840,6 +843,9 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
             if (t.sp == 0) t.cur = RT_CODE_NEXT_MODEL;
             else t.cur = stackBase[(--t.sp) * RT_WAVE];
         }
+#ifdef RT_TRAV_WATCHDOG /* experiment builds only: a traversal that does not end (a bug in a variant under test) ends wrong instead of hanging the GPU */
+        if (++watchdog > (1u << 18)) { t.cur = RT_CODE_DONE; t.sp = 0; t.cand = 0; }
+#endif
         RT_TRAV_VOTE();
     } while ((nA + nB + nC) * RT_SUSPEND_DEN > enteredNum);
 #undef RT_TRAV_VOTE

@@ -44,7 +44,8 @@ def run(plain, cfg, seed, mode):
     frames = 0
     for r in range(rounds):
         how = int(rng.integers(0, 4))
-        n = int(rng.integers(1, 40)) if how else int(rng.choice([1, 15, 16, 17, 31, 32, 33, 2, 18]))
+        # (round 5: fused launches hold 16 ... 64 frames, the cap follows the measured frame time: batches around every boundary)
+        n = int(rng.integers(1, 40)) if how else int(rng.choice([1, 15, 16, 17, 31, 32, 33, 2, 18, 47, 48, 49, 63, 64, 65, 100, 129]))
         if how == 0:
             mgr.RenderFrames(n)                       # rt_render_frames(n): full fused launches + the remainder
         elif how == 1:
