@@ -53,6 +53,11 @@ import __graft_entry__ as graft  # noqa: E402
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK = 256 * 4 * 2.4e9 / 2.0          # wave64 VALU instructions / s: 256 CUs x 4 SIMD-32, 2 cycles each
 N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9
+N_CU = 256
+# The vector-memory path's roof (round 5; tools/ubench/vmem_gather.hip, profiles/r05_memory_path.txt): a CU's L1 (TCP) takes about ONE
+# access per clock — a wave64 load is charged one access per group of neighbouring lanes that fall into one 128-byte line, 64 accesses in
+# 64.4 clocks when every lane has its own line — and no fewer than ~16 clocks per load instruction.  The BVH kernels sit at 0.83-0.92.
+L1_ACCESS_PEAK = N_CU * CLOCK_HZ * 1.0
 KERNEL_LIKE = "%rt_trace%kernel<false%"    # the non-stats instantiations (whole-frame and half-frame names)
 
 
@@ -310,6 +315,14 @@ def collect_pmc(config, steps, warmup, with_traffic, fpl=16):
             r["valu_types"] = {"arith": m1["SQ_INSTS_VALU_ADD_F32"]["avg"] + m1["SQ_INSTS_VALU_MUL_F32"]["avg"] + m1["SQ_INSTS_VALU_FMA_F32"]["avg"],
                                "trans": m1["SQ_INSTS_VALU_TRANS_F32"]["avg"], "int32": m2["SQ_INSTS_VALU_INT32"]["avg"],
                                "int64": m2["SQ_INSTS_VALU_INT64"]["avg"], "cvt": m2["SQ_INSTS_VALU_CVT"]["avg"]}
+        # the vector-memory path (round 5): L1 (TCP) accesses and TA busy cycles per launch, with the launch's own cycle count
+        mp = run_pmc_pass(["TCP_TOTAL_CACHE_ACCESSES_sum", "TA_BUSY_avr", "GRBM_GUI_ACTIVE", "SQ_INSTS_VMEM_RD"], config, steps, warmup, out, "mp", fpl)
+        if mp and "TCP_TOTAL_CACHE_ACCESSES_sum" in mp and "GRBM_GUI_ACTIVE" in mp:
+            cycles = mp["GRBM_GUI_ACTIVE"]["avg"] / 8.0          # the counter sums the 8 XCDs
+            r["memory_path"] = {"l1_accesses_per_launch": mp["TCP_TOTAL_CACHE_ACCESSES_sum"]["avg"], "gpu_cycles_per_launch": cycles,
+                                "l1_accesses_per_clk_per_cu": mp["TCP_TOTAL_CACHE_ACCESSES_sum"]["avg"] / N_CU / cycles,
+                                "ta_busy": (mp["TA_BUSY_avr"]["avg"] / cycles) if "TA_BUSY_avr" in mp else None,
+                                "l1_accesses_per_vmem_read_inst": (mp["TCP_TOTAL_CACHE_ACCESSES_sum"]["avg"] / mp["SQ_INSTS_VMEM_RD"]["avg"]) if mp.get("SQ_INSTS_VMEM_RD", {}).get("avg") else None}
         if with_traffic:
             rd = run_pmc_pass(["FETCH_SIZE"], config, steps, warmup, out, "rd", fpl)
             wr = run_pmc_pass(["WRITE_SIZE"], config, steps, warmup, out, "wr", fpl)
@@ -393,6 +406,21 @@ def peak_at_mix(pmc, variant):
     return {"cycles_per_valu_inst_at_mix": cpi_mix, "peak_at_mix": N_SIMD * CLOCK_HZ / cpi_mix / 1e9,
             "valu_type_shares": {b: counts[b] / max(1.0, total) for b in counts},
             "bucket_cycles_per_inst": {b: cpi.get(b) for b in counts}}
+
+
+def memory_path_roofline(pmc, launch_ms):
+    """The second roof of the trace kernels: L1 accesses per second against one access per clock per CU (see L1_ACCESS_PEAK).  For the
+    BVH workloads this, not VALU issue, is the binding one: 0.83-0.92 accesses per clock per CU, TA 71-85 % busy."""
+    mp = pmc.get("memory_path")
+    if not mp:
+        return None
+    achieved = mp["l1_accesses_per_launch"] / (launch_ms * 1e-3)
+    return {"bound": "l1_access", "achieved": achieved / 1e9, "peak": L1_ACCESS_PEAK / 1e9, "unit": "G L1 accesses/s", "frac": achieved / L1_ACCESS_PEAK,
+            "frac_at_measured_clock": mp["l1_accesses_per_clk_per_cu"], "ta_busy": mp["ta_busy"],
+            "l1_accesses_per_vmem_read_inst": mp["l1_accesses_per_vmem_read_inst"], "l1_accesses_per_launch": mp["l1_accesses_per_launch"],
+            "peak_derivation": "256 CUs x 2.4 GHz x 1 L1 (TCP) access per clock: tools/ubench/vmem_gather.hip measures 64 accesses of a wave64 global_load_dwordx4 "
+                               "(every lane its own 128-byte line) in 64.4 clocks and one access per group of neighbouring lanes in one line (profiles/r05_vmem_gather_ubench.txt, "
+                               "r05_vmem_gather_counters.txt); frac_at_measured_clock uses the launch's own GRBM_GUI_ACTIVE cycles instead of 2.4 GHz"}
 
 
 def valu_roofline(pmc, launch_ms, segments_per_launch, variant="bvh"):
@@ -679,6 +707,7 @@ def main():
         if pmc is not None:
             roof = valu_roofline(pmc, launch_ms, launch_segments, "flat" if args.config <= 2 else "bvh")
             roof["frames_per_launch"] = fpl
+            roof["memory_path"] = memory_path_roofline(pmc, launch_ms)
             roof["kernel"] = (f"rt_trace_kernel<false, *>, launches of {fpl} frames ((tile, frame) work items; one kernel per launch on one "
                               "stream in the roofline pass) — the form the timed K back-to-back rt_render_frame calls are launched in")
             roof["peak_derivation"] = "256 CU x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)"
@@ -747,6 +776,7 @@ def main():
                     continue
                 r2 = valu_roofline(p2, ms2, seg2)
                 r2["frames_per_launch"] = 16
+                r2["memory_path"] = memory_path_roofline(p2, ms2)   # the binding roof of the BVH workloads
                 r2["mrays_per_s_fused_launches"] = seg2 / (ms2 * 1e-3) / 1e6
                 r2["workload"] = f"{sc2.name}: {sc2.width}x{sc2.height}, {sc2.unique_triangles()} triangles, BASELINE.json configs[{cfg - 1}]"
                 if cfg == 3 and not args.no_cpu_baseline:

@@ -126,7 +126,7 @@ class Acc:
         return tot * k
 
 
-def traverse_loop(chains_of, acc, lanes_idx, thr_num, thr_den, burst=3, swap=None, thr_abs=None):
+def traverse_loop(chains_of, acc, lanes_idx, thr_num, thr_den, burst=3, swap=None, thr_abs=None, leaf_in_burst=0):
     """chains_of(i) -> the chain of lane i that is traversing (or None).  swap(i) -> tries to bring in lane i's
     other chain when the active one is finished; returns the new traversing chain or None."""
     def active_list():
@@ -158,6 +158,14 @@ def traverse_loop(chains_of, acc, lanes_idx, thr_num, thr_den, burst=3, swap=Non
                 acc.run("B", len(served))
                 for c in served:
                     c.step()
+                if leaf_in_burst:  # round 5: a lane that reaches a small leaf tests it inside the burst instead of waiting for a C vote
+                    small = [c for c in served if c.state == "T" and c.phase() == "C" and c.toks[c.pos] <= leaf_in_burst]
+                    if small:
+                        rem = [c.toks[c.pos] for c in small]
+                        for k in range(max(rem)):
+                            acc.run("C", sum(1 for r in rem if r > k))
+                        for c in small:
+                            c.step()
         else:
             served = [c for _, c in act if c.phase() == "C"]
             rem = [c.toks[c.pos] for c in served]
@@ -180,7 +188,7 @@ def traverse_loop(chains_of, acc, lanes_idx, thr_num, thr_den, burst=3, swap=Non
             break
 
 
-def sim_base(pixels, tiles_per_wave):
+def sim_base(pixels, tiles_per_wave, leaf_in_burst=0):
     acc = Acc()
     pool = list(pixels[: tiles_per_wave * 64])
     lanes = [Chain() for _ in range(64)]
@@ -209,7 +217,7 @@ def sim_base(pixels, tiles_per_wave):
             for c in b:
                 c.begin()
                 acc.segments += 1
-        traverse_loop(lambda i: lanes[i], acc, idx, 3, 8)
+        traverse_loop(lambda i: lanes[i], acc, idx, 3, 8, leaf_in_burst=leaf_in_burst)
         s = [c for c in lanes if c.state == "S"]
         shade_stage(s, acc)
     return acc

@@ -80,10 +80,9 @@ K(mullit, OP_MULLIT) K(addlit, OP_ADDLIT) K(fmalit, OP_FMALIT) K(fmak, OP_FMAK) 
 K(mad64, OP_MAD64) K(lshladd64, OP_LSHLADD64) K(lshl64, OP_LSHL64)
 K(fma, OP_FMA) K(mullo, OP_MULLO) K(mul24, OP_MUL24) K(mad24, OP_MAD24) K(xorb, OP_XOR) K(lshr, OP_LSHR) K(lshladd, OP_LSHLADD) K(addu, OP_ADDU)
 K(cvt, OP_CVT) K(rcp, OP_RCP) K(rsq, OP_RSQ) K(mov, OP_MOV) K(bfe, OP_BFE) K(andor, OP_ANDOR)
-template <typename F> void run(const char* name, F kern, float* d, unsigned long long* clocks)
+template <typename F> void run(const char* name, F kern, float* d, unsigned long long* clocks, int blocks, const char* mode)
 {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const int blocks = 256 * 8; // 8 waves per SIMD
     kern<<<blocks, 256>>>(d, 1.0001f, N_ITER, clocks); hipDeviceSynchronize();
     hipEventRecord(e0); kern<<<blocks, 256>>>(d, 1.0001f, N_ITER, clocks); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -92,15 +91,19 @@ template <typename F> void run(const char* name, F kern, float* d, unsigned long
     hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[2]; hipMemcpy(h, clocks, sizeof(h), hipMemcpyDeviceToHost);
     const double ghz = (double)h[0] / ((double)h[1] / 100e6) / 1e9; /* shader cycles / seconds of the 100 MHz counter, wave 0's life */
-    double waveInstr = (double)blocks * 4 * (double)iters * 8;
-    printf("%-14s %8.3f ms  clock %.3f GHz -> %5.2f cycles per wave64 instruction per SIMD\n", name, ms, ghz, ms * 1e-3 * ghz * 1e9 * 1024 / waveInstr);
+    /* every resident wave issues iters x 8 instructions; a SIMD holds wavesPerSimd of them: cycles per instruction per SIMD = the kernel's cycles (wave 0's
+     * own count) / (iters x 8 x waves per SIMD) */
+    const int wavesPerSimd = blocks >= 2048 ? 8 : 1;
+    printf("%-7s %-14s %8.3f ms  clock %.3f GHz -> %5.2f cycles per wave64 instruction per SIMD\n", mode, name, ms, ghz, (double)h[0] / ((double)iters * 8 * wavesPerSimd));
     fflush(stdout);
 }
 int main()
 {
     float* d; hipMalloc(&d, 256 * 8 * 256 * 4);
     unsigned long long* clocks; hipMalloc(&clocks, 16);
-#define R(n) run(#n, k_##n, d, clocks);
+    /* two loads: `chip` = 2,048 workgroups, every SIMD of the chip holds 8 waves (the power-limited sustained rate); `sparse` = 16 workgroups, one wave per
+     * SIMD on 16 CUs, 8 independent chains per lane (what a SIMD can issue when the chip is not power-limited) */
+#define R(n) run(#n, k_##n, d, clocks, 16, "sparse"); run(#n, k_##n, d, clocks, 2048, "chip");
     R(mad64) R(lshladd64) R(lshl64) R(mul) R(mullit) R(addlit) R(fmalit) R(fmak) R(mulinl) R(fmac) R(muls) R(sub) R(fma) R(fmas) R(pkmul) R(pkmuls) R(pkadd) R(pkfma) R(pkfmas) R(min) R(max) R(min3) R(max3) R(med3) R(cnd) R(cnds) R(cmp) R(cmps) R(minu) R(maxi) R(mul64) R(subs) R(mulneg) R(maxabs) R(mov) R(xorb) R(lshr) R(lshladd) R(addu) R(bfe) R(andor) R(mullo) R(mul24) R(mad24) R(cvt) R(rcp) R(rsq)
     return 0;
 }
