@@ -383,31 +383,6 @@ def launch_profile(pkg, api, dev_index, scene_id, W, H, launches, frames_per_lau
     return c["gpuMs"] / launches, c["segments"] / launches
 
 
-def peak_at_mix(pmc, variant):
-    """The VALU issue rate this kernel could reach if nothing but VALU issue limited it, AT ITS OWN INSTRUCTION MIX: the 2-cycle
-    wave64 rate behind `peak` holds for fp32 add / mul / fma on VGPR operands only (profiles/r03_valu_op_rates.txt).  Dynamic
-    instruction types come from the hardware (SQ_INSTS_VALU_ADD/MUL/FMA_F32, _TRANS_F32, _INT32, _INT64, _CVT; the rest = moves, logic,
-    compares, selects, min / max); the cost of each bucket = its static class make-up in the kernel's ISA (tools/isa_mix.py ->
-    profiles/isa_mix.json: which adds carry an SGPR source, which integer / other instructions are base class)."""
-    types = pmc.get("valu_types")
-    path = os.path.join(ROOT, "profiles", "isa_mix.json")
-    if not types or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        mix = json.load(f).get(variant)
-    if not mix:
-        return None
-    total = pmc["valu_insts_per_launch"]
-    counts = dict(types)
-    counts["other"] = max(0.0, total - sum(types.values()))
-    cpi = mix["cycles_per_instruction"]
-    cycles = sum(counts[b] * cpi.get(b, mix["static_cycles_per_instruction"]) for b in counts)
-    cpi_mix = cycles / max(1.0, total)
-    return {"cycles_per_valu_inst_at_mix": cpi_mix, "peak_at_mix": N_SIMD * CLOCK_HZ / cpi_mix / 1e9,
-            "valu_type_shares": {b: counts[b] / max(1.0, total) for b in counts},
-            "bucket_cycles_per_inst": {b: cpi.get(b) for b in counts}}
-
-
 def memory_path_roofline(pmc, launch_ms):
     """The second roof of the trace kernels: L1 accesses per second against one access per clock per CU (see L1_ACCESS_PEAK).  For the
     BVH workloads this, not VALU issue, is the binding one: 0.83-0.92 accesses per clock per CU, TA 71-85 % busy."""
@@ -431,15 +406,16 @@ def valu_roofline(pmc, launch_ms, segments_per_launch, variant="bvh"):
          "valu_insts_per_segment": pmc["valu_insts_per_launch"] / max(1, segments_per_launch),
          "counters": "replayed: " + pmc["replayed_from"] if "replayed_from" in pmc else
                      f"rocprofv3 --pmc passes over a child run of this script, in this invocation ({pmc.get('launches_sampled')} launches)"}
-    pm = peak_at_mix(pmc, variant)
-    if pm:
-        # frac_at_mix = share of the VALU issue capacity AT THIS MIX that the kernel uses: ~1 means the VALU pipes are saturated and
-        # only fewer instructions (or more useful lanes per instruction: lane_util) can make it faster
-        r.update({"peak_at_mix": pm["peak_at_mix"], "cycles_per_valu_inst_at_mix": pm["cycles_per_valu_inst_at_mix"],
-                  "valu_busy_at_mix": achieved / 1e9 / pm["peak_at_mix"], "frac_at_mix": achieved / 1e9 / pm["peak_at_mix"] * pmc["lane_util"],
-                  "valu_type_shares": pm["valu_type_shares"],
-                  "peak_at_mix_derivation": "1024 SIMD x 2.4 GHz / sum over hardware-counted instruction types of (share x cycles per wave64 instruction of that "
-                                            "type's static class make-up in this kernel: profiles/isa_mix.json, profiles/r03_valu_op_rates.txt)"})
+    if pmc.get("valu_types"):   # the hardware's dynamic instruction types, as shares (informational)
+        total = pmc["valu_insts_per_launch"]
+        shares = {k: v / max(1.0, total) for k, v in pmc["valu_types"].items()}
+        shares["other"] = max(0.0, 1.0 - sum(shares.values()))
+        r["valu_type_shares"] = shares
+    # (rounds 3-4 also printed `peak_at_mix` / `valu_busy_at_mix`: the 2-cycle peak re-priced with per-class issue costs from a microbenchmark.
+    # Round 5 re-measured those costs at the kernel's own clock in >= 20 ms kernels: they depend on how many waves the microbenchmark keeps
+    # resident and on the chip's power state (fp32 mul 2.9 -> 3.5 cycles, one wave per SIMD: 7.5), not on the instruction alone, and a busy
+    # fraction of 1.04 was the result.  Dropped: `valu_busy` at the architectural 2-cycle rate is the measurement; what binds the BVH kernels
+    # is `memory_path`.  profiles/r05_valu_op_rates.txt)
     if pmc.get("hbm_read_bytes") is not None and pmc.get("hbm_write_bytes") is not None:
         r["traffic"] = pmc["hbm_read_bytes"] + pmc["hbm_write_bytes"]
         r["hbm_physical"] = {"bytes_per_launch": r["traffic"], "GBps": r["traffic"] / (launch_ms * 1e-3) / 1e9,
