@@ -2,7 +2,7 @@
 utilisation 1 in every phase) against the shipped schedule, same scenes, same library build (make coherent).
 A coherent frame does 64x the work per pixel (4 frames per launch there).   usage: python tools/coherent_bound.py [configs]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as g
 os.environ["RT_HIP_LIB"] = os.path.join(g.PKG_DIR, "lib", "libraytrace_hip_coherent.so")
 pkg = g.load_package(); api = pkg.load_library()

@@ -1,7 +1,7 @@
 """The driver's timed pattern on config 2 (W warm-up RenderFrame() calls, synchronise, K x rt_render_frame, synchronise), alone, for
 `rocprofv3 --kernel-trace` timelines (tools/timeline.py).  usage: python tools/k20_pattern.py [K=20] [W=5] [config=2]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as g
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 20

@@ -1,6 +1,6 @@
 """Emulate one rank of an N-GPU strong-scaling run (partition 0 of N) and sweep the persistent grid size."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as g
 pkg = g.load_package(); api = pkg.load_library()
 cfg = int(sys.argv[1]); parts = int(sys.argv[2])

@@ -1,7 +1,7 @@
 """One GPU rendering partition 1/N of config C with rt_render_frames(k) for k = 1, 2, 4, 8, 16 frames per launch.
 usage: python tools/partition_frames.py <config> <N>   (on the GPU box)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as g
 pkg = g.load_package(); api = pkg.load_library()
 cfg, n = int(sys.argv[1]), int(sys.argv[2])

@@ -7,7 +7,7 @@ the wave's traversal lanes, the others wait in per-wave index queues between sta
 usage: python tools/sched_sim_queued.py scratch/trace_cfg4.npz"""
 import sys
 import os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tools/: sched_sim2.py
 from sched_sim2 import COST, Acc, Chain, parse, sim_base, shade_stage
 
 OVH = dict(TLOAD=30, TSTORE=25, SLOAD=45, ISTORE=40, CLOAD=35, SAVE=50)

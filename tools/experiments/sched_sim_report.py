@@ -4,7 +4,7 @@ usage: python tools/sched_sim_report.py scratch/trace_cfg3.npz [more traces]  > 
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tools/: sched_sim2.py
 import sched_sim2 as S  # noqa: E402
 
 for path in sys.argv[1:]:

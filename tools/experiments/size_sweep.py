@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as g
 pkg = g.load_package(); api = pkg.load_library()
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2

@@ -3,7 +3,7 @@
 Every iteration must count exactly the same segments (the frame index is pinned); prints the number of deviating iterations.
     python tools/stress_counters.py [procs] [iters]       (RT_HIP_LIB selects the library)"""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 def child(iters):
