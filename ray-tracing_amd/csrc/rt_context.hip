@@ -32,11 +32,13 @@
 /* Frames per fused launch: a budget, not a constant.  A launch ends with a tail as long as one pixel chain, so short
  * frames want many per launch (a rank that renders 1/8 of config 2: 0.108 ms per frame, 7.9 work items per resident wave at 16 frames);
  * long frames must not turn into launches that last seconds.  RT_FUSE_MIN frames always; more — up to RT_FUSE_MAX — while the launch
- * stays under RT_FUSE_TARGET_MS at the frame time MEASURED on the previous fused launches (stop-event to stop-event, polled, never
- * waited for).  BVH scenes (>= 4 ms per frame) stay at 16.  RT_FUSE_CAP=n pins it. */
+ * stays under RT_FUSE_TARGET_MS at the frame time MEASURED on the previous fused launches (stop event to stop event — or, for a launch
+ * without a predecessor, its own start to stop — polled, never waited for).  BVH scenes (>= 1.3 ms per frame) stay at 16.  RT_FUSE_CAP=n
+ * pins it. */
 #define RT_FUSE_MIN 16
 #define RT_FUSE_MAX 64
-#define RT_FUSE_TARGET_MS 9.0
+#define RT_FUSE_TARGET_MS 20.0
+#define RT_FUSE_SLAB_BYTES ((size_t)1536 << 20) /* a staging slab: 16 bytes per pixel and frame; 1920x1080: 45 frames, 3840x2160: 16 (2.1 GB), an eighth of 1080p: 64 */
 #include "rt_layout.h"
 #define RT_VERSION_STRING "raytrace_hip gfx950 abi=1"
 
@@ -127,7 +129,7 @@ struct RtContext {
     int fuseCap = RT_FUSE_MIN;  /* frames per fused launch right now (see RT_FUSE_MIN) */
     bool fuseCapPinned = false; /* RT_FUSE_CAP */
     /* the stop event of each fused launch's trace kernel; ms per frame = (stop - previous launch's stop) / frames once both have passed */
-    struct FuseProbe { hipEvent_t stop = nullptr; int frames = 0; int prev = -1; bool live = false; } fuseProbe[6];
+    struct FuseProbe { hipEvent_t start = nullptr, stop = nullptr; int frames = 0; int prev = -1; bool live = false; } fuseProbe[6];
     int fuseLast = -1;
     int gridOverride = 0; /* test hook: force the persistent grid size */
     bool stats = false;
@@ -419,7 +421,7 @@ void rt_destroy(RtContext* ctx)
         if (st.host) hipHostFree(st.host);
         if (st.done) hipEventDestroy(st.done);
     }
-    for (auto& fp : ctx->fuseProbe) if (fp.stop) hipEventDestroy(fp.stop);
+    for (auto& fp : ctx->fuseProbe) { if (fp.start) hipEventDestroy(fp.start); if (fp.stop) hipEventDestroy(fp.stop); }
     if (ctx->evStart) hipEventDestroy(ctx->evStart);
     if (ctx->evStop) hipEventDestroy(ctx->evStop);
     if (ctx->ord.evFork) hipEventDestroy(ctx->ord.evFork);
@@ -1712,9 +1714,11 @@ static int prepare_staging(RtContext* ctx, KArgs& a, int nFrames, size_t nPix, i
             hipFree(ctx->dStaging[b]);
             ctx->dStaging[b] = nullptr;
             ctx->stagingBytes[b] = 0;
-            /* RT_FUSE_MAX frames when that is small (a partition of the image), the present cap otherwise (re-made if the cap grows) */
-            size_t capFrames = (size_t)(ctx->fuseCap > nFrames ? ctx->fuseCap : nFrames);
-            if ((size_t)RT_FUSE_MAX * nPix * 16 <= ((size_t)768 << 20)) capFrames = RT_FUSE_MAX;
+            /* room for the largest batch this context will ever form, so that a growing cap never re-makes a slab in the middle of a
+             * render: as many frames as fit RT_FUSE_SLAB_BYTES, between RT_FUSE_MIN and RT_FUSE_MAX (the cap is held to what the slabs hold) */
+            size_t capFrames = nPix ? RT_FUSE_SLAB_BYTES / (nPix * 16) : RT_FUSE_MAX;
+            capFrames = capFrames < RT_FUSE_MIN ? RT_FUSE_MIN : capFrames > RT_FUSE_MAX ? RT_FUSE_MAX : capFrames;
+            if (capFrames < (size_t)nFrames) capFrames = (size_t)nFrames;
             const size_t cap = capFrames * nPix * 16;
             size_t got = cap;
             if (hipMalloc(&ctx->dStaging[b], cap) != hipSuccess) {
@@ -1778,28 +1782,50 @@ static RtContext::Tuner::Probe* tune_launch(RtContext* ctx, KArgs& a, bool stage
         for (auto& fp : ctx->fuseProbe) {
             if (!fp.live || hipEventQuery(fp.stop) != hipSuccess) continue;
             fp.live = false;
-            if (fp.prev < 0 || fp.frames <= 0) continue;
+            if (fp.frames <= 0) continue;
             float ms = 0;
-            /* (a slot re-recorded by a later launch gives a negative or failing difference: skipped) */
-            if (hipEventElapsedTime(&ms, ctx->fuseProbe[fp.prev].stop, fp.stop) != hipSuccess || !(ms > 0)) { (void)hipGetLastError(); continue; }
+            /* the previous fused launch's end to this one's; no predecessor (the first fused launch, a chain broken by full probes): its own
+             * start to its end (includes what it waited for the other stream's kernels: over-estimates, i.e. errs towards shorter batches).
+             * (a slot re-recorded by a later launch gives a negative or failing difference: skipped) */
+            hipEvent_t from = fp.prev >= 0 ? ctx->fuseProbe[fp.prev].stop : fp.start;
+            if (!from || hipEventElapsedTime(&ms, from, fp.stop) != hipSuccess || !(ms > 0)) { (void)hipGetLastError(); continue; }
             const double perFrame = (double)ms / fp.frames;
             int cap = (int)ceil(RT_FUSE_TARGET_MS / perFrame);
             cap = cap < RT_FUSE_MIN ? RT_FUSE_MIN : cap > RT_FUSE_MAX ? RT_FUSE_MAX : cap;
+            {   /* never more than the staging slabs hold (they are sized once, prepare_staging) */
+                const size_t nPixNow = (size_t)ctx->localRows * ctx->W;
+                size_t slab = 0;
+                for (int b = 0; b < 2; b++)
+                    if (ctx->stagingBytes[b] && (slab == 0 || ctx->stagingBytes[b] < slab)) slab = ctx->stagingBytes[b];
+                if (nPixNow && slab) {
+                    const size_t holds = slab / (nPixNow * 16);
+                    if ((size_t)cap > holds) cap = holds < RT_FUSE_MIN ? RT_FUSE_MIN : (int)holds;
+                }
+            }
             if (cap != ctx->fuseCap && ctx->verbose) fprintf(stderr, "[raytrace_hip] fused launches: %.3f ms per frame -> up to %d frames per launch\n", perFrame, cap);
             ctx->fuseCap = cap;
         }
     return probe;
 }
-static void mark_fused_launch_end(RtContext* ctx, hipStream_t st, int nFrames)
+/* around the trace kernel of a fused launch: returns the probe slot (or -1) */
+static int mark_fused_launch_begin(RtContext* ctx, hipStream_t st)
 {
-    if (ctx->fuseCapPinned) return;
+    if (ctx->fuseCapPinned) return -1;
     int slot = -1;
     for (int i = 0; i < (int)(sizeof(ctx->fuseProbe) / sizeof(ctx->fuseProbe[0])); i++)
         if (!ctx->fuseProbe[i].live && i != ctx->fuseLast) { slot = i; break; }
-    if (slot < 0) { ctx->fuseLast = -1; return; } /* all in flight: the chain of stop events breaks here */
+    if (slot < 0) { ctx->fuseLast = -1; return -1; } /* all in flight: the chain of stop events breaks here */
     RtContext::FuseProbe& fp = ctx->fuseProbe[slot];
-    if (!fp.stop) hipEventCreate(&fp.stop);
-    if (fp.stop && hipEventRecord(fp.stop, st) == hipSuccess) {
+    if (!fp.stop) { hipEventCreate(&fp.start); hipEventCreate(&fp.stop); }
+    if (!fp.start || !fp.stop) return -1;
+    if (ctx->fuseLast < 0 && hipEventRecord(fp.start, st) != hipSuccess) return -1; /* only a launch without a predecessor needs its own start */
+    return slot;
+}
+static void mark_fused_launch_end(RtContext* ctx, int slot, hipStream_t st, int nFrames)
+{
+    if (slot < 0) return;
+    RtContext::FuseProbe& fp = ctx->fuseProbe[slot];
+    if (hipEventRecord(fp.stop, st) == hipSuccess) {
         fp.frames = nFrames;
         fp.prev = ctx->fuseLast; /* its event stays recorded (a slot is reused only when it is not the last one) */
         fp.live = true;
@@ -1856,11 +1882,12 @@ static int enqueue_trace(RtContext* ctx, KArgs& a, const LaunchPlan& plan, int t
         if (!staged && (rc = LaunchOrder::before_acc_write(ctx, q, parts == 1))) return rc; /* the trace kernel itself adds into the accumulation buffer (RCC:20-23) */
         bool ownQueue = false;
         if ((rc = exp_pre_launch(ctx, exp_of(ctx), a, q, st, staged, tiles, &ownQueue))) return rc;
+        const int fuseSlot = staged ? mark_fused_launch_begin(ctx, st) : -1;
         if (probe) hipEventRecord(probe->start, st);
         hipLaunchKernelGGL(parts == 2 ? plan.kernHalf : plan.kern, dim3(grid), dim3(plan.blockThreads), plan.ldsBytes, st, a);
         if (probe) { hipEventRecord(probe->stop, st); probe->live = true; }
         HIP_TRY(ctx, hipGetLastError()); /* a refused launch ran no wave: the device counter did not move */
-        if (staged) mark_fused_launch_end(ctx, st, nFrames);
+        mark_fused_launch_end(ctx, fuseSlot, st, nFrames);
         if ((rc = exp_post_launch(ctx, exp_of(ctx), q, st))) return rc;
         /* every tile not taken by blockIdx is one successful fetch, and each of the grid waves overshoots once */
         if (!ownQueue) ctx->tileQueueNext[q] += (unsigned long long)items + (a.queueStart ? (unsigned long long)grid : 0ull);
