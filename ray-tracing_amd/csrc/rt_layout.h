@@ -24,12 +24,14 @@
 #define RT_LAYOUT_H
 
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <string>
@@ -402,6 +404,17 @@ struct LayoutEngine {
     bool run(const RtLayout& L, PodVec<DPair>& canonStore, LaidOutScene& out)
     {
         if (L.dense()) return run_dense(canonStore, out);
+        /* RT_DEBUG_UPLOAD: where the time of a layout goes */
+        const bool timing = getenv("RT_DEBUG_UPLOAD") != nullptr;
+        auto tPrev = std::chrono::steady_clock::now();
+#define RT_LAYOUT_T(what)                                                                                                      \
+        do {                                                                                                                   \
+            if (timing) {                                                                                                      \
+                const auto now = std::chrono::steady_clock::now();                                                             \
+                fprintf(stderr, "[rt] layout: %-16s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tPrev).count()); \
+                tPrev = now;                                                                                                   \
+            }                                                                                                                  \
+        } while (0)
         /* instances = distinct (root, triOffset), in the order the models name them */
         std::vector<Inst> insts;
         {
@@ -424,7 +437,9 @@ struct LayoutEngine {
             const size_t i1 = ((size_t)b + 1) << 16 < nCanon ? ((size_t)b + 1) << 16 : nCanon;
             for (size_t i = (size_t)b << 16; i < i1; i++) owner[i].store(-1, std::memory_order_relaxed);
         });
+        RT_LAYOUT_T("owner init");
         par((int)insts.size(), [&](int k) { lay_instance(L, insts[k], k, owner.get()); });
+        RT_LAYOUT_T("walks");
         bool irregular = false;
         uint64_t pairCur = 0, triCur = 0, placedTris = 0;
         for (Inst& I : insts) {
@@ -487,6 +502,7 @@ struct LayoutEngine {
             }
         }
 
+        RT_LAYOUT_T("codes");
         /* the buffers: zeroed (padding, the normals' holes under pair records) and filled in parallel */
         const size_t pairBytes = (size_t)pairCur * RT_UNIT_BYTES, triBytes = (size_t)triCur * RT_UNIT_BYTES;
         const size_t normBytes = (size_t)(arena ? pairCur : triCur) * RT_NORM_BYTES_PER_UNIT;
@@ -496,9 +512,27 @@ struct LayoutEngine {
             const size_t blk = (size_t)4 << 20;
             par((int)((n + blk - 1) / blk), [&](int b) { memset(p + (size_t)b * blk, 0, (size_t)(b + 1) * blk < n ? blk : n - (size_t)b * blk); });
         };
-        par_zero(out.pairBuf.data(), out.pairBuf.size());
-        if (!arena) par_zero(out.triBuf.data(), out.triBuf.size());
-        par_zero(out.normBuf.data(), out.normBuf.size());
+        /* the arena without pair alignment has no padding inside an instance's region: every unit is a pair's or a triangle's and is
+         * written below (a pair also zeroes its 48 bytes of the normal space); only the few units between two regions are zeroed here —
+         * no pass over 200 MB of fresh pages for a million triangles.  Every other layout pads: zero everything first. */
+        const bool noPadding = arena && !L.pairAlign;
+        if (noPadding) {
+            uint64_t end = 0;
+            for (const Inst& I : insts) {
+                if (I.pairBase > end) {
+                    memset(out.pairBuf.data() + (size_t)end * RT_UNIT_BYTES, 0, (size_t)(I.pairBase - end) * RT_UNIT_BYTES);
+                    memset(out.normBuf.data() + (size_t)end * RT_NORM_BYTES_PER_UNIT, 0, (size_t)(I.pairBase - end) * RT_NORM_BYTES_PER_UNIT);
+                }
+                end = I.pairBase + I.pairUnits;
+            }
+            if ((size_t)end * RT_UNIT_BYTES < out.pairBuf.size()) memset(out.pairBuf.data() + (size_t)end * RT_UNIT_BYTES, 0, out.pairBuf.size() - (size_t)end * RT_UNIT_BYTES);
+            if ((size_t)end * RT_NORM_BYTES_PER_UNIT < out.normBuf.size()) memset(out.normBuf.data() + (size_t)end * RT_NORM_BYTES_PER_UNIT, 0, out.normBuf.size() - (size_t)end * RT_NORM_BYTES_PER_UNIT);
+        } else {
+            par_zero(out.pairBuf.data(), out.pairBuf.size());
+            if (!arena) par_zero(out.triBuf.data(), out.triBuf.size());
+            par_zero(out.normBuf.data(), out.normBuf.size());
+        }
+        RT_LAYOUT_T("alloc + zero");
         unsigned char* const triSpace = arena ? out.pairBuf.data() : out.triBuf.data();
         /* work items: (instance, block of its pairs) and (instance, block of its leaves) */
         struct Item { int k; bool leaves; size_t a, b; };
@@ -518,6 +552,7 @@ struct LayoutEngine {
                     d.codeA = (d.codeA & RT_CODE_LEAF) ? leafCode[2 * (size_t)i] : unitOf[d.codeA];
                     d.codeB = (d.codeB & RT_CODE_LEAF) ? leafCode[2 * (size_t)i + 1] : unitOf[d.codeB];
                     memcpy(out.pairBuf.data() + (size_t)unitOf[i] * RT_UNIT_BYTES, &d, sizeof(d));
+                    if (noPadding) memset(out.normBuf.data() + (size_t)unitOf[i] * RT_NORM_BYTES_PER_UNIT, 0, RT_PAIR_UNITS * RT_NORM_BYTES_PER_UNIT);
                 }
             } else {
                 for (size_t a = it.a; a < it.b; a++) {
@@ -533,7 +568,9 @@ struct LayoutEngine {
                 }
             }
         });
+        RT_LAYOUT_T("fill");
         canonStore.resize_uninit(0);
+        RT_LAYOUT_T("free canonical");
         return true;
     }
 };
