@@ -12,8 +12,9 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_bench_n1*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r03_bench_n1*.json"))
-               + glob.glob(os.path.join(ROOT, "profiles", "r04_bench_n1*.json")))
+               + glob.glob(os.path.join(ROOT, "profiles", "r04_bench_n1*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r05_bench_n1*.json")))
 R04 = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_bench_n1*.json")))
+R05 = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_bench_n1*.json")))
 MULTI = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_bench_n[28]_*.json")))
 
 
@@ -34,7 +35,7 @@ def test_required_fields(path):
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
-        if key == "cpu_baseline" and "_config" in os.path.basename(path) and ("r03" in os.path.basename(path) or "r04" in os.path.basename(path)):
+        if key == "cpu_baseline" and "_config" in os.path.basename(path) and any(r in os.path.basename(path) for r in ("r03", "r04", "r05")):
             continue   # the round-3 lines of the other configs were taken with --no-cpu-baseline (the headline line has it)
         assert key in d, key
         assert isinstance(d[key], typ), (key, type(d[key]))
@@ -72,7 +73,7 @@ def test_roofline_object(path):
 def test_cpu_baseline_and_parity_objects(path):
     d = load(path)
     if "cpu_baseline" not in d:
-        assert "_config" in os.path.basename(path) and ("r03" in os.path.basename(path) or "r04" in os.path.basename(path))
+        assert "_config" in os.path.basename(path) and any(r in os.path.basename(path) for r in ("r03", "r04", "r05"))
         assert d["parity"]["bit_identical"] is True
         return
     c = d["cpu_baseline"]
@@ -111,6 +112,41 @@ def test_round4_roofline_is_self_consistent(path):
     assert os.path.exists(os.path.join(ROOT, "profiles", "r04_fetch_size_calibration.txt")) and os.path.exists(os.path.join(ROOT, "profiles", "isa_mix.json"))
     if "scene_load" in d:      # lines of the final build: the scene set-up (GPU BVH forest + upload) is reported beside the timed region
         assert d["scene_load"]["ms"] > 0 and d["scene_load"]["bvh_build_ms"] >= 0 and "outside the timed region" in d["scene_load"]["what"]
+
+
+def test_round5_lines_exist():
+    names = {os.path.basename(p) for p in R05}
+    assert {"r05_bench_n1.json", "r05_bench_n1_k20.json", "r05_bench_n1_config3.json", "r05_bench_n1_config4.json", "r05_bench_n1_config5.json",
+            "r05_bench_n1_config6.json"} <= names
+
+
+@pytest.mark.parametrize("path", R05, ids=[os.path.basename(p) for p in R05])
+def test_round5_roofs_and_reference_text_parity(path):
+    """(weak 3 / item 6) a busy fraction cannot exceed 1 — the `*_at_mix` construct is gone from the line; (item 1) the roof that binds
+    the BVH kernels is in the line: L1 accesses per second against one per clock per CU, measured in the run; (item 4) the headline image is compared in the run with
+    the reference's text + the declared sphere hook, the BVH configs with the reference's text."""
+    d = load(path)
+    assert d["diagnostics"] == [] and d["value"] is not None
+    r = d["roofline"]
+    assert not [k for k in r if k.endswith("_at_mix")]
+    assert 0.0 < r["valu_busy"] <= 1.0 and 0.0 < r["lane_util"] <= 1.0 and math.isclose(r["frac"], r["valu_busy"] * r["lane_util"], rel_tol=1e-6)
+    mp = r["memory_path"]
+    assert mp["bound"] == "l1_access" and mp["unit"] == "G L1 accesses/s" and math.isclose(mp["peak"], 256 * 2.4, rel_tol=1e-9)
+    assert math.isclose(mp["achieved"], mp["l1_accesses_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel_tol=1e-6)
+    assert math.isclose(mp["frac"], mp["achieved"] / mp["peak"], rel_tol=1e-9)
+    assert 0.0 < mp["frac"] <= 1.0 and 0.0 < mp["frac_at_measured_clock"] <= 1.0 and 0.0 < mp["ta_busy"] <= 1.0
+    headline = "_config" not in os.path.basename(path)
+    if headline:
+        assert mp["frac"] < 0.4 and r["valu_busy"] > 0.6          # the sphere scene: VALU issue binds, the memory path idles
+    else:
+        assert mp["frac"] > 0.75 and mp["frac"] > r["frac"]        # the BVH scenes: at the chip's gather rate
+    ref = d["parity"]["vs_reference_text"]
+    assert ref["bit_identical"] is True and ref["max_rel_err"] == 0.0 and ref["same_strips"] is True
+    assert ("libref_spheres.so" in ref["library"]) is headline and ("libref.so" in ref["library"]) is (not headline)
+    if headline and "secondary" in d:
+        for cfg in ("config3", "config4"):
+            assert d["secondary"][cfg]["memory_path"]["frac"] > 0.75
+        assert d["secondary"]["config3"]["cpu_baseline"]["kind"] == "reference" and d["cpu_baseline"]["kind"] == "port"
 
 
 @pytest.mark.parametrize("path", MULTI, ids=[os.path.basename(p) for p in MULTI])

@@ -851,3 +851,36 @@ def test_pinned_frames_per_fused_launch(pkg, api, monkeypatch):
     tr = api.create_tracer(0)
     assert tr.fused_frames_cap() == 5
     tr.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["dense", "pre", "hot=5", "align", "arena", "pre,arena,palign", "pre,hot=3,arena"])
+def test_every_record_layout_renders_the_same_bits(pkg, api, orc, layout, monkeypatch):
+    """Round 5: the kernels address every record by the 16-byte unit it starts at, so where the records lie (RT_LAYOUT,
+    ray-tracing_amd/csrc/rt_layout.h) is a host-side choice that cannot change a bit: images and exact counters of a mesh scene with depth of
+    field and of a many-mesh scene equal the oracle's under every layout (the default, `pre,arena`, is what every other test runs)."""
+    monkeypatch.setenv("RT_LAYOUT", layout)
+    for cfg, kw, (w, h), frames in ((4, {"subdivisions": 3}, (96, 54), 2), (5, {"subdivisions": 2, "n_meshes": 5}, (80, 45), 1)):
+        out = []
+        for lib, tr in ((api, api.create_tracer(0)), (orc, orc.create_tracer(8))):
+            if lib is api:
+                tr.enable_stats(True)
+            mgr = pkg.scenes.get(cfg, **kw).make_manager(tr, lib, w, h)
+            mgr.OnEnable(renderSeed=4)
+            mgr.RenderFrames(frames)
+            out.append((tr.read_accumulated(), tr.counters()))
+            tr.close()
+        (a, ca), (b, cb) = out
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (layout, cfg)
+        for k in ("segments", "innerSteps", "leafSteps", "triTests", "modelVisits"):
+            assert ca[k] == cb[k], (layout, cfg, k, ca[k], cb[k])
+
+
+@pytest.mark.gpu
+def test_unknown_layout_is_refused_at_upload(pkg, api, monkeypatch):
+    monkeypatch.setenv("RT_LAYOUT", "arenas")
+    tr = api.create_tracer(0)
+    mgr = pkg.scenes.get(3).make_manager(tr, api, 32, 18)
+    with pytest.raises(pkg.abi.RtError):
+        mgr.OnEnable(renderSeed=1)
+    tr.close()
