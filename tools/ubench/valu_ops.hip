@@ -91,10 +91,11 @@ template <typename F> void run(const char* name, F kern, float* d, unsigned long
     hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[2]; hipMemcpy(h, clocks, sizeof(h), hipMemcpyDeviceToHost);
     const double ghz = (double)h[0] / ((double)h[1] / 100e6) / 1e9; /* shader cycles / seconds of the 100 MHz counter, wave 0's life */
-    /* every resident wave issues iters x 8 instructions; a SIMD holds wavesPerSimd of them: cycles per instruction per SIMD = the kernel's cycles (wave 0's
-     * own count) / (iters x 8 x waves per SIMD) */
-    const int wavesPerSimd = blocks >= 2048 ? 8 : 1;
-    printf("%-7s %-14s %8.3f ms  clock %.3f GHz -> %5.2f cycles per wave64 instruction per SIMD\n", mode, name, ms, ghz, (double)h[0] / ((double)iters * 8 * wavesPerSimd));
+    /* `sparse` (one wave per SIMD): wave 0's own cycles / its iters x 8 instructions = the issue interval of ONE wave.
+     * `chip`: the kernel's time x the measured clock x 1,024 SIMDs / all wave-instructions — total work over total time, whatever number of waves
+     * the SIMDs really keep resident (round 5's first version divided wave 0's cycles by an assumed eight: void) */
+    const double perSimd = blocks >= 2048 ? ms * 1e-3 * ghz * 1e9 * 1024.0 / ((double)blocks * 4 * (double)iters * 8) : (double)h[0] / ((double)iters * 8);
+    printf("%-7s %-14s %8.3f ms  clock %.3f GHz -> %5.2f cycles per wave64 instruction per SIMD\n", mode, name, ms, ghz, perSimd);
     fflush(stdout);
 }
 int main()
