@@ -8,11 +8,12 @@
  * computed with the same fp32 operation the reference's per-ray code performs
  * (RayCommon.hlsl:190-192 are ray-independent):
  *
- *  DPair (64 B, 64-B aligned): both children of one inner node — the only
+ *  DPair (64 B, 16-B aligned): both children of one inner node — the only
  *      thing RayTriangleBVH (RC:262-282) reads per inner step — with each
  *      child's (startIndex, triangleCount) pre-decoded into a 32-bit "code",
  *      so a popped entry never re-reads its own node (reference: 96 B per
- *      inner step; here: one aligned 64-B record).
+ *      inner step; here: one 64-B record).  Where the records lie — every one
+ *      is named by the 16-byte unit it starts at — is rt_layout.h's choice.
  *  DTri (48 B = 3 x float4): posA, edgeAB, edgeAC, cross(edgeAB, edgeAC).
  *  DTriN (36 B): the three vertex normals, read once per segment for the
  *      winning triangle only (the reference normalises a normal per test and

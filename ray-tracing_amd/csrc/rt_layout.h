@@ -3,7 +3,7 @@
  * replays it on the CPU).
  *
  * SceneBuilder::convert (rt_context.hip) validates the caller's BVHs and emits them in a CANONICAL form: node pairs in
- * post-order with pair INDICES in the inner codes and triangle INDICES in the leaf codes.  apply_layout() turns that into
+ * post-order with pair INDICES in the inner codes and triangle INDICES in the leaf codes.  LayoutEngine::run() turns that into
  * what the kernels address (rt_device.h): every record is named by the 16-byte UNIT it starts at —
  *     inner code = unit of the DPair in the pair space, leaf code = first unit of the leaf's run of DTri records relative
  *     to the model's triBase (three units per triangle), normals = 12 bytes per unit of the triangle space —
