@@ -512,26 +512,11 @@ struct LayoutEngine {
             const size_t blk = (size_t)4 << 20;
             par((int)((n + blk - 1) / blk), [&](int b) { memset(p + (size_t)b * blk, 0, (size_t)(b + 1) * blk < n ? blk : n - (size_t)b * blk); });
         };
-        /* the arena without pair alignment has no padding inside an instance's region: every unit is a pair's or a triangle's and is
-         * written below (a pair also zeroes its 48 bytes of the normal space); only the few units between two regions are zeroed here —
-         * no pass over 200 MB of fresh pages for a million triangles.  Every other layout pads: zero everything first. */
-        const bool noPadding = arena && !L.pairAlign;
-        if (noPadding) {
-            uint64_t end = 0;
-            for (const Inst& I : insts) {
-                if (I.pairBase > end) {
-                    memset(out.pairBuf.data() + (size_t)end * RT_UNIT_BYTES, 0, (size_t)(I.pairBase - end) * RT_UNIT_BYTES);
-                    memset(out.normBuf.data() + (size_t)end * RT_NORM_BYTES_PER_UNIT, 0, (size_t)(I.pairBase - end) * RT_NORM_BYTES_PER_UNIT);
-                }
-                end = I.pairBase + I.pairUnits;
-            }
-            if ((size_t)end * RT_UNIT_BYTES < out.pairBuf.size()) memset(out.pairBuf.data() + (size_t)end * RT_UNIT_BYTES, 0, out.pairBuf.size() - (size_t)end * RT_UNIT_BYTES);
-            if ((size_t)end * RT_NORM_BYTES_PER_UNIT < out.normBuf.size()) memset(out.normBuf.data() + (size_t)end * RT_NORM_BYTES_PER_UNIT, 0, out.normBuf.size() - (size_t)end * RT_NORM_BYTES_PER_UNIT);
-        } else {
-            par_zero(out.pairBuf.data(), out.pairBuf.size());
-            if (!arena) par_zero(out.triBuf.data(), out.triBuf.size());
-            par_zero(out.normBuf.data(), out.normBuf.size());
-        }
+        /* zero first, in parallel 4-MB blocks: padding, the normals' holes under pair records — and the first touch of the fresh pages by ONE
+         * thread per block (filling without it, sixteen threads faulting the same 2-MB pages, measured 20 % slower on a million triangles) */
+        par_zero(out.pairBuf.data(), out.pairBuf.size());
+        if (!arena) par_zero(out.triBuf.data(), out.triBuf.size());
+        par_zero(out.normBuf.data(), out.normBuf.size());
         RT_LAYOUT_T("alloc + zero");
         unsigned char* const triSpace = arena ? out.pairBuf.data() : out.triBuf.data();
         /* work items: (instance, block of its pairs) and (instance, block of its leaves) */
@@ -552,7 +537,6 @@ struct LayoutEngine {
                     d.codeA = (d.codeA & RT_CODE_LEAF) ? leafCode[2 * (size_t)i] : unitOf[d.codeA];
                     d.codeB = (d.codeB & RT_CODE_LEAF) ? leafCode[2 * (size_t)i + 1] : unitOf[d.codeB];
                     memcpy(out.pairBuf.data() + (size_t)unitOf[i] * RT_UNIT_BYTES, &d, sizeof(d));
-                    if (noPadding) memset(out.normBuf.data() + (size_t)unitOf[i] * RT_NORM_BYTES_PER_UNIT, 0, RT_PAIR_UNITS * RT_NORM_BYTES_PER_UNIT);
                 }
             } else {
                 for (size_t a = it.a; a < it.b; a++) {
