@@ -230,3 +230,73 @@ def test_shared_nodes_with_other_triangles_fall_back_to_dense(env):
         lay = api.layout_arrays(models2, tris2, nodes, layout)
         assert lay["used"] == "dense"
         walk_and_check(models2, tris2, nodes, lay)
+
+
+def _random_forest(pkg, rng, n_meshes, share):
+    """Hand-made node / triangle buffers (not from a BVH builder): random binary trees whose leaves name random — possibly overlapping,
+    possibly repeated — triangle ranges; `share` adds two models over the first mesh's nodes, one with the same and one with ANOTHER
+    triangle offset: all of it is input rt_upload_scene accepts."""
+    abi = pkg.abi
+    nodes, models = [], []
+    n_tris = int(rng.integers(40, 120))
+    tris = np.zeros(n_tris * (n_meshes + 1), dtype=abi.triangle_dtype)
+    for k in ("posA", "posB", "posC", "normA", "normB", "normC"):
+        tris[k] = rng.uniform(-1, 1, (len(tris), 3)).astype(np.float32)
+    roots = []
+    for m in range(n_meshes):
+        node_off = len(nodes)
+        tri_off = m * n_tris
+
+        def leaf():
+            c = int(rng.integers(1, 6))
+            s = int(rng.integers(0, n_tris - c))
+            return dict(startIndex=s, triangleCount=c)
+
+        # node list with placeholders, children allocated in adjacent pairs (the reference's layout, BVH:94-101)
+        local = [None]
+        work = [(0, 0)]
+        while work:
+            at, depth = work.pop()
+            if depth >= 1 and (depth >= 6 or rng.random() < 0.35):
+                local[at] = leaf()
+                continue
+            first = len(local)
+            local += [None, None]
+            local[at] = dict(startIndex=first, triangleCount=-1)   # inner: BVH.cs marks it with -1
+            work += [(first, depth + 1), (first + 1, depth + 1)]
+        for nd in local:
+            rec = np.zeros(1, dtype=abi.node_dtype)[0]
+            rec["boundsMin"] = rng.uniform(-2, 0, 3)
+            rec["boundsMax"] = rng.uniform(0, 2, 3)
+            rec["startIndex"], rec["triangleCount"] = nd["startIndex"], nd["triangleCount"]
+            nodes.append(rec)
+        roots.append((node_off, tri_off))
+    for node_off, tri_off in roots:
+        mi = np.zeros(1, dtype=abi.model_dtype)[0]
+        mi["nodeOffset"], mi["triOffset"] = node_off, tri_off
+        models.append(mi)
+    if share:  # more models over the first mesh's nodes: share == 1 with the same triangles, share == 2 also with other triangles
+        for tri_off in (roots[0][1], n_meshes * n_tris)[:share]:
+            mi = np.zeros(1, dtype=abi.model_dtype)[0]
+            mi["nodeOffset"], mi["triOffset"] = roots[0][0], tri_off
+            models.append(mi)
+    for mi in models:
+        mi["worldToLocal"] = np.eye(4, dtype=np.float32).T.reshape(-1)
+        mi["localToWorld"] = np.eye(4, dtype=np.float32).T.reshape(-1)
+    return np.array(models, dtype=abi.model_dtype), tris, np.array(nodes, dtype=abi.node_dtype)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_node_graphs_under_every_layout(env, seed):
+    """Fuzz: whatever buffers rt_upload_scene accepts, every layout either lays them out so that the walk from each model's root meets the
+    caller's boxes and triangles, or declines (-> dense) — never a wrong record.  Overlapping and repeated leaf ranges are placed again
+    (each leaf its own run); models that share nodes with the SAME triangles share records; with OTHER triangles the scene is irregular."""
+    pkg, api = env
+    rng = np.random.default_rng(1000 + seed)
+    share = seed % 3
+    models, tris, nodes = _random_forest(pkg, rng, int(rng.integers(1, 5)), share)
+    for layout in ("dense", "pre,arena", "arena", "hot=2,align", "pre,hot=3,arena,palign"):
+        lay = api.layout_arrays(models, tris, nodes, layout)
+        assert lay["used"] == ("dense" if share == 2 else layout)   # the same nodes under two triangle offsets: irregular
+        n_pairs, n_tris = walk_and_check(models, tris, nodes, lay)
+        assert n_tris > 0
