@@ -1,5 +1,6 @@
 """Extended run of the random-scene fuzz of tests/test_gpu_fuzz.py: seeds [first, first + n) through the shipped and the stats kernel
 instantiations against the CPU oracle — images bit for bit, exact work counters, no root-filter violation.
+RT_FUZZ_SECONDS=s stops taking new seeds after s seconds (a bounded GPU lease) and reports what was done.
 usage: python tools/scene_fuzz.py [n=200] [first=1000]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +13,12 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 pkg = g.load_package(); api = pkg.load_library(); orc = g.load_oracle()
 bad, t0, segs = 0, time.time(), 0
+budget = float(os.environ.get("RT_FUZZ_SECONDS", "0"))
+last = first - 1
 for seed in range(first, first + n):
+    if budget and time.time() - t0 > budget:
+        break
+    last = seed
     out = []
     for lib, tr, stats in F._three(api, orc):
         sc, render_seed = F.random_scene(pkg, seed)
@@ -32,5 +38,5 @@ for seed in range(first, first + n):
     except AssertionError as e:
         bad += 1
         print("MISMATCH", str(e)[:300])
-print(f"SCENE FUZZ {'OK' if not bad else 'MISMATCH x %d' % bad}: seeds {first}..{first + n - 1}, {segs} segments compared, {time.time() - t0:.0f} s")
+print(f"SCENE FUZZ {'OK' if not bad else 'MISMATCH x %d' % bad}: seeds {first}..{last}, {segs} segments compared, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
