@@ -159,6 +159,7 @@ struct RtContext {
     size_t stagingBytes[2] = {0, 0};
     bool stagingUnavailable = false; /* the slab could not be allocated at this image size: fused launches go out frame by frame (cleared by rt_resize) */
     int stagedNext = 0;              /* stream / slab of the next fused launch */
+    bool fusedBehindFirstPart = true; /* RT_FUSED_BEHIND_FIRST_PART=0: plain alternation also after a two-part frame (A/B switch) */
     bool alternate = true;           /* fused launches alternate between the two streams; off while the second slab does not fit (until the next rt_resize) */
     bool alternateWanted = true;     /* RT_ALTERNATE=0: every fused launch on the main stream (round-3 behaviour) */
     /* ---- everything the context's two render streams wait for ACROSS each other, in one place (the rules: LaunchOrder's functions below)
@@ -360,6 +361,7 @@ int rt_create(int device_id, RtContext** out)
     if (getenv("RT_VERBOSE")) ctx->verbose = true;
     if (const char* f = getenv("RT_FUSE_FRAMES")) ctx->fuseFrames = atoi(f) != 0;
     if (const char* l = getenv("RT_LPT")) ctx->lptEnabled = atoi(l) != 0;
+    if (const char* l = getenv("RT_FUSED_BEHIND_FIRST_PART")) ctx->fusedBehindFirstPart = atoi(l) != 0;
     if (const char* t = getenv("RT_TWO_STREAMS")) ctx->twoStreams = atoi(t) != 0;
     if (const char* c = getenv("RT_COALESCE")) ctx->coalesce = atoi(c) != 0;
     if (const char* fg = getenv("RT_FRAME_GROUP")) ctx->frameGroupOverride = atoi(fg);
@@ -1958,6 +1960,10 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
     if (staged) {
         if ((rc = enqueue_accumulate(ctx, a, nFrames, nPix, lane))) return rc;
         if (twoOwn && ctx->alternate) ctx->stagedNext = 1 - lane;
+    } else if (parts == 2 && ctx->fusedBehindFirstPart) {
+        /* a fused launch that follows a two-part frame goes behind the part that started first and ends first (the main stream's), so
+         * its waves take the slots the other part's drain leaves empty instead of waiting for that drain to end */
+        ctx->stagedNext = 0;
     }
     ctx->pixelFrames += (uint64_t)ctx->localRows * ctx->W * nFrames;
     ctx->lastLaunched += nFrames;
