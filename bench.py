@@ -31,6 +31,10 @@ counters come from rocprofv3 PMC passes over a child run of THIS script in the s
 for the SQ counters, FETCH_SIZE and WRITE_SIZE); if rocprofv3 is unavailable the committed profiles/ summary
 is replayed and labelled so.
 
+Before the W warm-up steps the render runs untimed for --spinup-ms (default 40) of GPU load — ordinary frames of the
+same accumulation — because this GPU's clocks ramp for 20-30 ms after idling and the driver's 3 + 13 ms of warm-up
+and timed region would end inside the ramp (profiles/r05_clock_ramp.txt); reported in the line as `spinup`.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse

@@ -179,3 +179,17 @@ def test_bench_defaults_and_flags():
     assert args["--gpus"] == 1 and args["--config"] == 2
     assert 1 <= args["--steps"] <= 200 and 0 <= args["--warmup"] <= 10
     assert args["--scaling"] == "strong"
+
+
+def test_round5_spinup_is_reported_and_switchable():
+    """The device spin-up (profiles/r05_clock_ramp.txt) is part of the line — frames, time, target — and --spinup-ms 0 turns it off; the A/B lines of the
+    final build are kept (on: 48 frames in 40 ms; off: 0 frames) and the steps / warm-up of the line stay the driver's."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"--spinup-ms"' in src and '"spinup": dict(spinup' in src and "accumulated[0] += spinup[\"frames\"]" in src
+    on = load(os.path.join(ROOT, "profiles", "r05_bench_n1_k20.json"))
+    assert on["steps"] == 20 and on["warmup"] == 5 and on["spinup"]["frames"] >= 4 and on["spinup"]["ms"] >= on["spinup"]["target_ms"] == 40.0
+    assert on["config"]["first_timed_frame"] == 1 + on["spinup"]["frames"] + on["warmup"]      # the reference counts frames from 1 (RCM:71)
+    offs = [load(p) for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_spinup_ab_k20_off_*.json")))]
+    assert len(offs) == 2 and all(o["spinup"]["frames"] == 0 and o["steps"] == 20 and o["warmup"] == 5 for o in offs)
+    assert all(o["config"]["first_timed_frame"] == 1 + 5 for o in offs)
+    assert os.path.exists(os.path.join(ROOT, "profiles", "r05_clock_ramp.txt"))
