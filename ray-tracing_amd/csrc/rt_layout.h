@@ -1,6 +1,6 @@
 /*
- * rt_layout.h — WHERE the traversal's records lie in device memory (internal, host side; plain C++: tools/layout_sim.cpp
- * replays it on the CPU).
+ * rt_layout.h — WHERE the traversal's records lie in device memory (internal, host side; plain C++: rt_debug_layout hands the
+ * result to tests/test_layout.py and to the line-touch model tools/layout_sim/ without a device).
  *
  * SceneBuilder::convert (rt_context.hip) validates the caller's BVHs and emits them in a CANONICAL form: node pairs in
  * post-order with pair INDICES in the inner codes and triangle INDICES in the leaf codes.  LayoutEngine::run() turns that into
