@@ -802,6 +802,7 @@ struct SceneBuilder {
     std::vector<uint32_t> bigLeaves;
     std::vector<int32_t> pairOfFirstChild; /* absolute first-child node index -> pair id, -1 unseen, -2 in progress */
     std::vector<int32_t> pairDepth;        /* height of the subtree below pair (levels) */
+    std::vector<int32_t> pairNodeOffset;   /* the nodeOffset the pair's inner children were resolved with (RC:265-266: child = nodeOffset + startIndex) */
     std::vector<long long> pairLeafEnd;    /* largest startIndex + triangleCount of the leaves below pair (mesh-relative) */
     std::string error;
     /* parallel conversion (one builder per mesh): pairs go into a segment of the scene's array, with their final ids; the memo
@@ -861,6 +862,10 @@ struct SceneBuilder {
                 int known = pairOfFirstChild[f.firstChild - memoLo];
                 if (known == -2) { error = "cycle in BVH node graph"; return false; }
                 if (known >= 0) {
+                    /* a pair with inner children means what it means under ONE nodeOffset (RC:265-266 adds the model's nodeOffset to a child
+                     * index): a mesh whose tree wanders into another mesh's nodes would need a second, different conversion of the same nodes —
+                     * refused like a cycle (the reference would traverse it; no builder produces it) */
+                    if (pairDepth[known - idBase] > 1 && pairNodeOffset[known - idBase] != nodeOffset) { error = "node pair reached under two different nodeOffsets"; return false; }
                     /* converted for an earlier model that shares these nodes: its leaves were range-checked
                      * against THAT model's triOffset, so check this one's against the subtree's largest leaf end */
                     if ((long long)triOffset + pairLeafEnd[known - idBase] > nTris) { error = "leaf triangle range out of bounds"; return false; }
@@ -908,6 +913,7 @@ struct SceneBuilder {
             }
             int h = 1 + (f.hA > f.hB ? f.hA : f.hB);
             pairDepth.push_back(h);
+            pairNodeOffset.push_back(nodeOffset);
             pairLeafEnd.push_back(f.endA > retEnd ? f.endA : retEnd);
             pairOfFirstChild[f.firstChild - memoLo] = id;
             retCode = (uint32_t)id;

@@ -162,7 +162,9 @@ def test_validate_scene_refuses_what_upload_scene_refuses(pkg, api, monkeypatch,
     off = info.copy()
     off[0]["nodeOffset"] = len(nodes)
     refused(off, tris, nodes, "out of range")
-    # a mesh that reaches into another mesh's nodes (outside its window) is still a valid scene: the sequential walk takes over
+    # a mesh that reaches into another mesh's nodes (outside its window) goes to the sequential walk — which refuses it when the grafted nodes would have to
+    # mean two things: a child index is the MODEL's nodeOffset + startIndex (RC:265-266), so inner nodes read under another offset are another tree (round 5;
+    # rounds 1-4 reused the first reading)
     if not sequential:
         other = next(i for i in range(len(info)) if int(info[i]["nodeOffset"]) != root)
         graft = nodes.copy()
@@ -173,8 +175,8 @@ def test_validate_scene_refuses_what_upload_scene_refuses(pkg, api, monkeypatch,
             try:
                 got = api.validate_scene_arrays(info, tris, graft, spheres)
                 assert got["n_pairs"] > 0
-            except a.RtError as e:      # only a triangle-range refusal is acceptable here (the grafted leaves use the other mesh's triOffset)
-                assert e.status == a.RT_ERR_SCENE and "out of bounds" in str(e)
+            except a.RtError as e:      # a triangle-range refusal (the grafted leaves use the other mesh's triOffset) or the two-offsets refusal
+                assert e.status == a.RT_ERR_SCENE and ("out of bounds" in str(e) or "two different nodeOffsets" in str(e))
 
 
 def test_validate_scene_fuzz_parallel_and_sequential_agree(pkg, api, monkeypatch):

@@ -300,3 +300,56 @@ def test_random_node_graphs_under_every_layout(env, seed):
         assert lay["used"] == ("dense" if share == 2 else layout)   # the same nodes under two triangle offsets: irregular
         n_pairs, n_tris = walk_and_check(models, tris, nodes, lay)
         assert n_tris > 0
+
+
+def test_corrupted_scenes_are_refused_or_laid_out_right(env):
+    """Fuzz on the boundary's trust: real scenes with a few node / model fields overwritten (child indices anywhere, leaf counts, node sharing, cycles, models
+    pointed at other meshes' nodes).  rt_upload_scene's preparation either refuses (RT_ERR_SCENE) or produces records whose walk is the reference's walk of
+    the caller's buffers (RC:234-287: child = the MODEL's nodeOffset + startIndex) — under every layout, never a crash, never a different tree."""
+    pkg, api = env
+    rng = np.random.default_rng(7)
+    base = [scene_arrays(pkg, api, c) for c in (3, (4, {"subdivisions": 2}), 6)]
+    walked = refused = 0
+    for it in range(400):
+        m, t, n = [a.copy() for a in base[it % len(base)]]
+        for _ in range(int(rng.integers(1, 6))):
+            what = int(rng.integers(0, 5))
+            i = int(rng.integers(0, len(n)))
+            if what == 0:
+                n["startIndex"][i] = int(rng.integers(-5, len(n) + 5))
+            elif what == 1:
+                n["triangleCount"][i] = int(rng.integers(-2, 200))
+            elif what == 2:
+                n["startIndex"][i] = int(rng.integers(0, len(n)))
+            elif what == 3:
+                m["nodeOffset"][int(rng.integers(0, len(m)))] = int(rng.integers(0, len(n)))
+            else:
+                m["triOffset"][int(rng.integers(0, len(m)))] = int(rng.integers(0, len(t) + 3))
+        layout = ("dense", "pre,arena", "hot=3,align", "pre,hot=4,arena,palign", "arena")[it % 5]
+        try:
+            lay = api.layout_arrays(m, t, n, layout)
+        except pkg.abi.RtError as e:
+            assert e.status == pkg.abi.RT_ERR_SCENE, e
+            refused += 1
+            continue
+        walk_and_check(m, t, n, lay)
+        walked += 1
+    assert walked > 100 and refused > 100, (walked, refused)
+
+
+def test_a_node_pair_under_two_node_offsets_is_refused(env):
+    """RC:265-266: a child index is the MODEL's nodeOffset + startIndex, so the same inner node means different children under different offsets.  A mesh whose
+    tree wanders into another mesh's nodes (round 5's fuzz: the conversion used to reuse the first model's reading of those nodes for the second) is refused."""
+    pkg, api = env
+    m, t, n = [a.copy() for a in scene_arrays(pkg, api, 3)]
+    offs = sorted(set(int(o) for o in m["nodeOffset"]))
+    big = max(offs, key=lambda o: (offs[offs.index(o) + 1] if offs.index(o) + 1 < len(offs) else len(n)) - o)   # the mesh with the most nodes
+    assert big != 0
+    inner = [i for i in range(big + 1, len(n)) if n["triangleCount"][i] <= 0 and any(n["triangleCount"][big + int(n["startIndex"][i]) + s] <= 0 for s in (0, 1))]
+    target = inner[len(inner) // 2]                # an inner node of that mesh whose children are not both leaves
+    first = target if (target - big) % 2 == 1 else target - 1   # sibling pairs start at odd distances from their mesh's root (BVH:94-101)
+    n["startIndex"][0] = first                                    # model 0's root (nodeOffset 0) now names a sibling pair inside the other mesh
+    assert n["triangleCount"][0] <= 0 and first > big
+    with pytest.raises(pkg.abi.RtError) as e:
+        api.layout_arrays(m, t, n, "dense")
+    assert e.value.status == pkg.abi.RT_ERR_SCENE and "two different nodeOffsets" in str(e.value)
