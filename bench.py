@@ -11,7 +11,8 @@ progressive render.  Scene and render targets are resident in HBM before the tim
 
 "rays" = path segments = CalculateRayCollision calls (RayCommon.hlsl:487), counted exactly by the kernel.
 `value` times K x rt_render_frame (the Dispatch only) issued back to back — the library holds frames requested
-while earlier ones still execute back (up to 16) and launches them fused, bit-identical to one launch per frame;
+while earlier ones still execute back (16 ... 64: a budget of ~20 ms per launch at the measured frame time) and launches them
+fused, bit-identical to one launch per frame;
 `value_one_kernel_per_frame` is the same work at exactly one kernel per frame (the roofline pass);
 `value_with_initframe` times K x the mirror's RenderFrame() = InitFrame (UpdateModels + SetShaderParams every
 frame, RCM:115-124) + Dispatch.
@@ -22,7 +23,8 @@ cyclic 8-row strips (no data-path collective), scaling is STRONG by default (the
 each rank renders 1/N of its rows); the one RCCL gather of the accumulation tiles happens at readback,
 after the timed steps, and is reported as `gather_ms`.  `--scaling weak` grows the image with N instead.
 
-roofline (rank 0, N = 1): the kernel is VALU-issue bound, not memory bound, so
+roofline (rank 0, N = 1): the headline kernel is VALU-issue bound, not memory bound (the BVH kernels of
+--config 3..6 are bound by the vector-memory path, reported beside it as `roofline.memory_path`), so
 `bound` = "valu": achieved = SQ_INSTS_VALU per launch / average launch time, peak = 256 CU x 4 SIMD x
 2.4 GHz / 2 cycles per wave64 instruction, frac = achieved/peak x lane utilisation
 (SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)).  A "launch" is the dominant one of the timed region: the
