@@ -33,15 +33,19 @@ counters come from rocprofv3 PMC passes over a child run of THIS script in the s
 for the SQ counters, FETCH_SIZE and WRITE_SIZE); if rocprofv3 is unavailable the committed profiles/ summary
 is replayed and labelled so.
 
-Before the W warm-up steps the render runs untimed for --spinup-ms (default 40) of GPU load — ordinary frames of the
-same accumulation — because this GPU's clocks ramp for 20-30 ms after idling and the driver's 3 + 13 ms of warm-up
-and timed region would end inside the ramp (profiles/r05_clock_ramp.txt); reported in the line as `spinup`.
+`value` is the driver's contract and nothing else: W warm-up steps, a barrier, exactly K timed steps, first timed Frame = W + 1 on every
+rank (asserted with an all_gather).  There is no hidden spin-up (round 5's wall-clock-bounded one made ranks render different frame
+counts).  This GPU's clocks do ramp for 20-30 ms after idling (profiles/r05_clock_ramp.txt), so a 13 ms region scatters by
++-5 %: the line therefore ALSO carries `regions` — R (default 7) further back-to-back regions of the same progressive render, each at
+least K steps and at least 50 ms long, each bracketed like the timed one — and `value_median_of_regions`, the figure A/B comparisons
+quote.  The number of steps per region is derived from an all-reduced time, so every rank renders the same frames.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import glob
 import json
+import math
 import os
 import shutil
 import socket
@@ -147,8 +151,12 @@ def cpu_baseline(pkg, scene_id, width, height, min_s=10.0, max_frames=4, threads
 def cpu_baseline_reference(pkg, scene_id, width, height, min_s=8.0, max_frames=2):
     """The REFERENCE'S OWN loop on one pinned host core: oracle/_ref/libref.so is the reference's shader text (RayCommon.hlsl +
     RayCompute.compute) compiled as C++ by oracle/make_ref.py in the container that has the reference checkout; it travels to the GPU box
-    as a prebuilt library.  Model-only scenes (the reference has no sphere buffer); None when the library is not there."""
-    ref = graft.load_ref()
+    as a prebuilt library.  A scene with analytic spheres (the headline) is timed on libref_spheres.so — the same text + the ONE declared
+    sphere hook S1 (the reference's own RaySphere called from the commented call site RC:341) — and says so: kind "reference+S1".
+    None when the library is not there."""
+    sc = pkg.scenes.get(scene_id)
+    variant = "spheres" if sc.spheres else ""
+    ref = graft.load_ref(variant)
     if ref is None:
         return None
     orc = graft.load_oracle()  # BVH builder + camera helper of the manager mirror (BVH.cs is C#, not part of the shader text)
@@ -158,8 +166,6 @@ def cpu_baseline_reference(pkg, scene_id, width, height, min_s=8.0, max_frames=2
         os.sched_setaffinity(0, {pinned})
     try:
         tr = ref.create_tracer(threads=1)
-        sc = pkg.scenes.get(scene_id)
-        sc.spheres = []
         mgr = sc.make_manager(tr, orc, width, height)
         mgr.OnEnable(renderSeed=1)
         tr.reset_counters()
@@ -174,8 +180,9 @@ def cpu_baseline_reference(pkg, scene_id, width, height, min_s=8.0, max_frames=2
     finally:
         if old:
             os.sched_setaffinity(0, old)
-    return {"value": c["segments"] / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
-            "sample": f"oracle/_ref/libref.so (the reference's HLSL text compiled as C++, g++ -O2, strict fp32), 1 thread pinned to cpu {pinned}: "
+    lib = "libref_spheres.so (the reference's HLSL text + the declared sphere hook S1, compiled as C++" if variant else "libref.so (the reference's HLSL text compiled as C++"
+    return {"value": c["segments"] / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference+S1" if variant else "reference",
+            "sample": f"oracle/_ref/{lib}, g++ -O2, strict fp32), 1 thread pinned to cpu {pinned}: "
                       f"frames 1..{frames} of the same scene at {width}x{height} ({c['segments']} segments in {dt:.1f} s)",
             "nproc": os.cpu_count()}
 
@@ -437,7 +444,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=65, help="timed frames (default 65: a progressive render's steady state = the first frame at once + 4 coalesced launches of 16)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--spinup-ms", type=float, default=40.0, help="untimed frames rendered before the warm-up steps until the GPU has been under load this long (clock ramp after idle; 0 = off)")
+    ap.add_argument("--regions", type=int, default=7, help="further timed regions after the K steps (each >= K steps and >= --region-ms long) -> value_median_of_regions; 0 = off")
+    ap.add_argument("--region-ms", type=float, default=50.0, help="minimum length of one of the --regions regions")
     ap.add_argument("--config", type=int, default=2, help="scene id (default 2 = the headline workload; 5 = the 8-GPU 3840x2160 case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the informational rt_render_frames(K) pass (profile runs)")
@@ -526,29 +534,24 @@ def main():
         mgr.numAccumulatedFrames = frame
         mgr.SetShaderParams()
 
-    # ---- device spin-up (before the W warm-up steps; --spinup-ms 0 switches it off): this GPU's clocks need 20-30 ms of load to come up
-    # after an idle period as short as 10 ms (profiles/r05_clock_ramp.txt: the same 20 frames take 13.2 ms right after 5 warm-up frames,
-    # 12.7 ms after 25, 12.2 ms after 45 — in fresh contexts on a GPU that was busy 10 ms earlier — whatever the tile order has learned).
-    # W = 5 steps of 0.6 ms end inside that ramp and so would the 13 ms timed region; the metric is a steady-state rate (the reference's
-    # numbers are averages over thousands of frames), so the progressive render simply starts earlier: these are ordinary
-    # frames of the same accumulation (the warm-up and timed frames follow them), rendered and counted, never timed.
-    spinup = {"frames": 0, "ms": 0.0, "target_ms": args.spinup_ms}
-    if args.spinup_ms > 0:
-        t_spin = time.perf_counter()
-        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms and spinup["frames"] < 4096:
-            for _ in range(4):
-                mgr.RenderFrame()
-            tracer.synchronize()
-            spinup["frames"] += 4
-        spinup["ms"] = (time.perf_counter() - t_spin) * 1e3
-        accumulated[0] += spinup["frames"]
-
     # ---- warmup
     for _ in range(args.warmup):
         mgr.RenderFrame()
     accumulated[0] += args.warmup
+    skew_ms = float(os.environ.get("RT_BENCH_RANK_SKEW_MS", "0") or 0)   # test hook: odd ranks fall behind by this much before every pass
+    def skew():
+        if skew_ms > 0 and rank % 2 == 1:
+            time.sleep(skew_ms * 1e-3)
+    skew()
     barrier()
     first_frame = tracer.frame()
+    if first_frame != 1 + args.warmup:
+        diagnostics.append(f"rank {rank}: first timed Frame is {first_frame}, expected 1 + warmup = {1 + args.warmup}")
+    if dist_on:   # every rank times the SAME frame indices (they seed the RNG, RC:552, and the gathered image adds them up per strip)
+        firsts = [None] * world
+        dist.all_gather_object(firsts, first_frame)
+        if len(set(firsts)) != 1:
+            diagnostics.append(f"rank {rank}: ranks disagree on the first timed Frame: {firsts}")
 
     # ---- timed: exactly K steps
     tracer.reset_counters()
@@ -567,9 +570,38 @@ def main():
     elapsed = t1 - t0
     segments = timed["segments"]
 
+    # ---- R further regions of the same progressive render (>= K steps and >= --region-ms each): the median is what a 1 % change shows up in
+    # (a single 13 ms region scatters by +-5 % with the device's clock ramp).  Steps per region from an ALL-REDUCED time: identical on every rank.
+    regions = None
+    if args.regions > 0:
+        job_elapsed = elapsed
+        if dist_on:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            job_elapsed = tt[0].item()
+        per_step = max(job_elapsed / args.steps, 1e-6)
+        region_steps = int(min(4096, max(args.steps, math.ceil(args.region_ms * 1e-3 / per_step))))
+        r_el, r_seg = [], []
+        for _ in range(args.regions):
+            skew()
+            tracer.reset_counters()
+            barrier()
+            r0 = time.perf_counter()
+            for _ in range(region_steps):
+                tracer.render_frame()
+            tracer.synchronize()
+            torch.cuda.synchronize()
+            r_el.append(time.perf_counter() - r0)
+            barrier()
+            r_seg.append(tracer.counters()["segments"])
+            accumulated[0] += region_steps
+        regions = {"n": args.regions, "steps_each": region_steps, "elapsed_s": r_el, "segments": r_seg,
+                   "first_frame": first_frame + args.steps}
+
     # ---- the same K frames through the host mirror's RenderFrame(): InitFrame + Dispatch per frame (RCM:84-95)
     mgr.numAccumulatedFrames = first_frame
     tracer.reset_counters()
+    skew()
     barrier()
     i0 = time.perf_counter()
     for _ in range(args.steps):
@@ -642,10 +674,13 @@ def main():
                 alpha = full[..., 3]
                 gather_alpha_ok = bool((alpha == float(accumulated[0])).all().item())
                 gathered = {"alpha_expected": accumulated[0], "alpha_min": float(alpha.min().item()), "alpha_max": float(alpha.max().item())}
+                if not gather_alpha_ok:   # a rank rendered other frames than rank 0 counted: the headline would describe an incoherent image
+                    diagnostics.append(f"rank 0: gathered image incomplete: alpha in [{gathered['alpha_min']}, {gathered['alpha_max']}], expected {accumulated[0]} everywhere")
             del full
         except Exception as e:  # the timed result stands on its own; report the collective's failure instead of losing the line
             gather_ms = None
             gather_error = f"{type(e).__name__}: {e}"
+            diagnostics.append(f"rank {rank}: gather: {gather_error}")
         # ---- and the gathered image itself against the oracle: a fresh progressive render of 2 frames on all ranks,
         # gathered, sample strips (one per rank at least) re-rendered by the CPU oracle on rank 0
         try:
@@ -683,6 +718,12 @@ def main():
         s = torch.tensor([segments, pkg.abi.algorithmic_bytes(stats, n_models, n_spheres)], dtype=torch.float64, device=comm_device)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         total_segments, total_bytes = s[0].item(), s[1].item()
+        if regions:
+            re_ = torch.tensor(regions["elapsed_s"], dtype=torch.float64, device=comm_device)
+            rs_ = torch.tensor([float(x) for x in regions["segments"]], dtype=torch.float64, device=comm_device)
+            dist.all_reduce(re_, op=dist.ReduceOp.MAX)
+            dist.all_reduce(rs_, op=dist.ReduceOp.SUM)
+            regions["elapsed_s"], regions["segments"] = re_.tolist(), rs_.tolist()
     else:
         kernel_ms_max = timed["gpuMs"]
         total_segments = float(segments)
@@ -726,8 +767,6 @@ def main():
             "value": total_segments / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "spinup": dict(spinup, what="untimed frames of the same progressive render BEFORE the W warm-up steps, until the GPU has been under load "
-                                        "target_ms (its clocks ramp for 20-30 ms after an idle period; profiles/r05_clock_ramp.txt); --spinup-ms 0 = off"),
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": args.scaling,
@@ -746,6 +785,7 @@ def main():
             "mpaths_per_s": W * H * spp * args.steps / elapsed / 1e6,
             "resolution": [W, H],
             "kernel_ms_per_step": kernel_ms_max / args.steps,
+            "value_median_of_regions": None, "regions": None,
             "value_with_initframe": total_segments / init_elapsed / 1e6,
             "ms_per_step_with_initframe": init_elapsed / args.steps * 1e3,
             "gather_ms": gather_ms, "gather_error": gather_error, "gathered_image_complete": gather_alpha_ok,
@@ -767,6 +807,15 @@ def main():
             "parity": parity if parity is not None else "checked at N=1 (pytest -m gpu and the N=1 bench line)",
             "roofline": roof,
         }
+        if regions:
+            vals = [sg / el / 1e6 for sg, el in zip(regions["segments"], regions["elapsed_s"])]
+            out["value_median_of_regions"] = sorted(vals)[len(vals) // 2]
+            out["regions"] = {"n": regions["n"], "steps_each": regions["steps_each"], "first_frame": regions["first_frame"],
+                              "values": vals, "min": min(vals), "max": max(vals),
+                              "ms_per_step_median": sorted(el / regions["steps_each"] * 1e3 for el in regions["elapsed_s"])[len(vals) // 2],
+                              "what": f"{regions['n']} further back-to-back regions of the same progressive render after the K timed steps, each {regions['steps_each']} steps "
+                                      f"(>= K and >= {args.region_ms:g} ms), each bracketed by barrier + synchronise like the timed one; max time over ranks, segments summed; "
+                                      "`value` stays the driver's W + K contract"}
         # ---- the same roofline for BVH workloads (north_star's roofline clause is about BVH traversal, RC:234-287)
         if not dist_on and args.config == 2 and not args.no_secondary:
             sec = {}
@@ -790,7 +839,18 @@ def main():
                 sec[f"config{cfg}"] = r2
             out["secondary"] = sec
         if not dist_on and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, args.config, W, H)
+            # the reference's own loop (its text; + the declared sphere hook S1 for a sphere scene) on one pinned core, a bounded sample: the
+            # same scene at 1/4 x 1/4 of the resolution for the headline (rays/s does not depend on the resolution to first order; one
+            # 1920x1080 frame would be ~45 s of this library); the builder's port stays beside it
+            port = cpu_baseline(pkg, args.config, W, H)
+            try:
+                refb = cpu_baseline_reference(pkg, args.config, max(8, W // 4), max(8, H // 4), min_s=10.0, max_frames=4)
+            except Exception as e:
+                refb = None
+                port["reference_leg_error"] = f"{type(e).__name__}: {e}"
+            out["cpu_baseline"] = refb if refb else port
+            if refb:
+                out["cpu_baseline_port"] = port
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             # informational: the same port on the host's cores (row bands of the image per thread)
             nthr = min(os.cpu_count() or 1, 64)

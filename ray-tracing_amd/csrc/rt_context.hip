@@ -121,7 +121,6 @@ struct RtContext {
      * fuseCap) and leave as ONE fused launch at the next call that needs them (flush_pending) */
     void* dPxCold = nullptr; /* pixel records of the resident waves: 2 launch slots (main / side stream) x pxColdWaves x 2 KB */
     long long pxColdWaves = 0;
-    struct ExperimentState* exp = nullptr; /* host state of the kernel experiments; null in the product build (see RT_EXPERIMENTS below) */
     int frameGroupOverride = 0; /* RT_FRAME_GROUP: frames per (tile, frame group) item of fused launches (tuning hook) */
     bool coalesce = true;  /* RT_COALESCE=0: every rt_render_frame launches at once */
     int pending = 0;       /* frames [frame - pending, frame) requested but not launched yet */
@@ -282,8 +281,6 @@ static int stage_upload(RtContext* ctx, void* dst, const void* src, size_t bytes
 
 static int launch_frames(RtContext* ctx, int frame0, int nFrames);
 static bool gpu_idle(RtContext* ctx);
-static void exp_create(RtContext* ctx);
-static void exp_release(RtContext* ctx);
 
 /* Launch the frames rt_render_frame held back.  Called first thing by every entry point that reads or changes
  * what those frames depend on, or that hands results to the host. */
@@ -370,7 +367,6 @@ int rt_create(int device_id, RtContext** out)
         const int v = atoi(fc);
         if (v >= 1) { ctx->fuseCap = v > RT_FUSE_MAX ? RT_FUSE_MAX : v; ctx->fuseCapPinned = true; }
     }
-    exp_create(ctx); /* the experiments' environment (nothing in the product build) */
     *out = ctx;
     return RT_OK;
 }
@@ -414,7 +410,6 @@ void rt_destroy(RtContext* ctx)
     for (int i = 0; i < 2; i++) if (ctx->ord.evAccWriter[i]) hipEventDestroy(ctx->ord.evAccWriter[i]);
     for (int i = 0; i < 2; i++) if (ctx->ord.evAccFull[i]) hipEventDestroy(ctx->ord.evAccFull[i]);
     hipFree(ctx->dPxCold);
-    exp_release(ctx);
     for (auto& pr : ctx->tuner.probe) {
         if (pr.start) hipEventDestroy(pr.start);
         if (pr.stop) hipEventDestroy(pr.stop);
@@ -1481,7 +1476,6 @@ static void fill_args(RtContext* ctx, int frame0, int nFrames, KArgs& a)
         const bool noNegZero = rt_f2u(o.x) != 0x80000000u && rt_f2u(o.y) != 0x80000000u && rt_f2u(o.z) != 0x80000000u;
         a.raygenNoDefocus = (a.defocus == 0.0f && fin && noNegZero && std::isfinite(a.rcpW)) ? 1 : 0;
     }
-    a.debugCoherent = getenv("RT_DEBUG_COHERENT") && atoi(getenv("RT_DEBUG_COHERENT")) ? 1 : 0;
     a.counters = ctx->dCounters;
 }
 
@@ -1500,26 +1494,8 @@ struct LaunchPlan {
     size_t ldsBytes = 0;
     int blockThreads = RT_WAVE;
     int variant = 0;             /* slot of the occupancy cache */
-    bool twoPartsAllowed = true; /* (an experiment kernel may want one kernel per launch) */
     long long resident = 0;      /* workgroups the chip keeps resident */
 };
-
-/* ---- the kernel experiments' host halves: ONE hook; the product build compiles the empty versions */
-#ifdef RT_EXPERIMENTS
-#include "experiments/rt_launch_experiments.inl"
-static void exp_create(RtContext* ctx) { ctx->exp = new ExperimentState(); exp_init(ctx, *ctx->exp); }
-static void exp_release(RtContext* ctx) { if (ctx->exp) { exp_destroy(*ctx->exp); delete ctx->exp; ctx->exp = nullptr; } }
-#else
-struct ExperimentState {};
-static void exp_create(RtContext*) {}
-static void exp_release(RtContext*) {}
-static int exp_choose(RtContext*, ExperimentState&, KArgs&, LaunchPlan&, bool) { return RT_OK; }
-static int exp_prepare(RtContext*, ExperimentState&, long long) { return RT_OK; }
-static int exp_pre_launch(RtContext*, ExperimentState&, KArgs&, int, hipStream_t, bool, int, bool* ownQueue) { *ownQueue = false; return RT_OK; }
-static int exp_post_launch(RtContext*, ExperimentState&, int, hipStream_t) { return RT_OK; }
-#endif
-static ExperimentState g_noExperiments;
-static inline ExperimentState& exp_of(RtContext* ctx) { return ctx->exp ? *ctx->exp : g_noExperiments; }
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * LaunchOrder — every wait between the context's two render streams (s = 0 main, 1 side), as named steps.
@@ -1636,8 +1612,6 @@ static int choose_variant(RtContext* ctx, KArgs& a, LaunchPlan& plan, bool* many
                     : many         ? (ctx->stats ? rtk::rt_trace_half_kernel<true, false, true> : rtk::rt_trace_half_kernel<false, false, true>)
                                    : (ctx->stats ? rtk::rt_trace_half_kernel<true, false> : rtk::rt_trace_half_kernel<false, false>);
     plan.variant = (ctx->flatScene ? 2 : many ? 4 : 0) + (ctx->stats ? 1 : 0);
-    int rc = exp_choose(ctx, exp_of(ctx), a, plan, many);
-    if (rc) return rc;
     if (ctx->occBytes[plan.variant] != plan.ldsBytes + 1) { /* occupancy query cached per (variant, LDS bytes) */
         int perCU = 0;
         HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, plan.kern, plan.blockThreads, plan.ldsBytes));
@@ -1660,7 +1634,7 @@ static int prepare_records(RtContext* ctx, const LaunchPlan& plan)
         HIP_TRY(ctx, hipMalloc(&ctx->dPxCold, (size_t)2 * waves * RT_COLD_STRIDE_BYTES));
         ctx->pxColdWaves = waves;
     }
-    return exp_prepare(ctx, exp_of(ctx), waves);
+    return RT_OK;
 }
 
 /* ---- prepare buffers: longest-chain-first queue order, learnt from the frames already rendered at this size.  Re-sorted once 1, 2, 4, 8,
@@ -1888,17 +1862,14 @@ static int enqueue_trace(RtContext* ctx, KArgs& a, const LaunchPlan& plan, int t
         int rc;
         if ((rc = LaunchOrder::before_order_read(ctx, q))) return rc;
         if (!staged && (rc = LaunchOrder::before_acc_write(ctx, q, parts == 1))) return rc; /* the trace kernel itself adds into the accumulation buffer (RCC:20-23) */
-        bool ownQueue = false;
-        if ((rc = exp_pre_launch(ctx, exp_of(ctx), a, q, st, staged, tiles, &ownQueue))) return rc;
         const int fuseSlot = staged ? mark_fused_launch_begin(ctx, st) : -1;
         if (probe) hipEventRecord(probe->start, st);
         hipLaunchKernelGGL(parts == 2 ? plan.kernHalf : plan.kern, dim3(grid), dim3(plan.blockThreads), plan.ldsBytes, st, a);
         if (probe) { hipEventRecord(probe->stop, st); probe->live = true; }
         HIP_TRY(ctx, hipGetLastError()); /* a refused launch ran no wave: the device counter did not move */
         mark_fused_launch_end(ctx, fuseSlot, st, nFrames);
-        if ((rc = exp_post_launch(ctx, exp_of(ctx), q, st))) return rc;
         /* every tile not taken by blockIdx is one successful fetch, and each of the grid waves overshoots once */
-        if (!ownQueue) ctx->tileQueueNext[q] += (unsigned long long)items + (a.queueStart ? (unsigned long long)grid : 0ull);
+        ctx->tileQueueNext[q] += (unsigned long long)items + (a.queueStart ? (unsigned long long)grid : 0ull);
         if (q == 1) LaunchOrder::side_used(ctx);
         if (!staged && (rc = LaunchOrder::after_acc_write(ctx, q, parts == 1))) return rc;
     }
@@ -1960,7 +1931,7 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
         }
     }
     RtContext::Tuner::Probe* probe = tune_launch(ctx, a, staged, nFrames);
-    const int parts = (!staged && twoOwn && tiles >= 2 && plan.twoPartsAllowed) ? 2 : 1;
+    const int parts = (!staged && twoOwn && tiles >= 2) ? 2 : 1;
     if ((parts == 2 || lane == 1) && (rc = LaunchOrder::fork_side(ctx))) return rc; /* the side stream follows what the main stream holds so far */
     if ((rc = enqueue_trace(ctx, a, plan, tiles, nFrames, lane, parts, probe))) return rc;
     if (staged) {
@@ -2265,9 +2236,6 @@ int rt_debug_phase_profile(RtContext* ctx, uint64_t* out, int n)
     }
     for (int p = 0; p < RT_N_PHASES && 2 * RT_N_PHASES + 1 + p < n; p++) { /* elapsed ticks per coarse phase: measurement build only, else 0 */
         out[2 * RT_N_PHASES + 1 + p] = 0;
-#ifdef RT_PHASE_TIMES
-        for (int s = 0; s < RT_COUNTER_SLOTS; s++) out[2 * RT_N_PHASES + 1 + p] += h[(size_t)s * RT_COUNTER_FIELDS + 8 + 2 * RT_N_PHASES + p];
-#endif
     }
     return RT_OK;
 }

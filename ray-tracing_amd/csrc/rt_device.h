@@ -33,16 +33,8 @@
 #define RT_PIXEL_FIELDS 4
 #define RT_N_PHASES 12
 /* bytes of a wave's record in KArgs::pxCold: two float4 per lane (+ the traversal stack in the RT_GLOBAL_STACK experiment) */
-#ifdef RT_GLOBAL_STACK
-#define RT_COLD_STRIDE_BYTES (2 * RT_WAVE * 16 + RT_STACK_DEPTH * RT_WAVE * 4)
-#else
 #define RT_COLD_STRIDE_BYTES (2 * RT_WAVE * 16)
-#endif
-#ifdef RT_PHASE_TIMES /* measurement build (make phase-times): + elapsed shader-clock ticks per coarse phase */
-#define RT_COUNTER_FIELDS (8 + 3 * RT_N_PHASES)
-#else
 #define RT_COUNTER_FIELDS (8 + 2 * RT_N_PHASES)
-#endif
 
 /* Every record of the traversal is named by the 16-byte UNIT it starts at (rt_layout.h decides where the records lie):
  * node codes: bit31 = leaf.  leaf: [30:24] = triangle count (1..127), [23:0] = first unit of the leaf's run of DTri records
@@ -54,21 +46,6 @@
 #define RT_CODE_MAX_INLINE_COUNT 127
 #define RT_CODE_MAX_INLINE_START 0x00ffffffu
 
-#ifdef RT_PAIR_FETCH
-/* two 32-byte halves, one child each: (min.xyz, code | max.xyz, -) — what ONE lane of a pair fetches in the pair-cooperative
- * inner step (rt_kernels.h) */
-struct DPair {
-    float aMin[3];
-    uint32_t codeA;
-    float aMax[3];
-    uint32_t pad0;
-    float bMin[3];
-    uint32_t codeB;
-    float bMax[3];
-    uint32_t pad1;
-};
-#define RT_PAIR_FORMAT 1
-#else
 struct DPair {
     float aMin[3], aMax[3];
     float bMin[3], bMax[3];
@@ -76,7 +53,6 @@ struct DPair {
     uint32_t pad[2];
 };
 #define RT_PAIR_FORMAT 0
-#endif
 struct DTri {
     float ax, ay, az, abx;
     float aby, abz, acx, acy;
@@ -167,9 +143,6 @@ struct KArgs {
     float rcpSpp;                /* 1 / NumRaysPerPixel   — RC:581 */
     int32_t suspendNum;          /* traverse() is left once active <= entered * suspendNum / 8 lanes are still traversing */
     int32_t raygenNoDefocus;     /* defocusStrength == 0, camera matrix finite, no component of the camera origin is -0 */
-    int32_t debugCoherent;       /* MEASUREMENT ONLY (RT_DEBUG_COHERENT=1): every idle lane of a wave is handed the SAME pixel, so all 64
-                                  * lanes run identical chains — the rate of a wave whose rays never diverge, i.e. the ceiling of any
-                                  * regrouping / compaction scheme.  The image is still correct (64 lanes write the same values). */
     /* counters: RT_COUNTER_SLOTS x RT_COUNTER_FIELDS u64 */
     unsigned long long* counters;
     /* persistent waves: this launch renders launchTiles tiles; its queue position q is entry
@@ -178,12 +151,6 @@ struct KArgs {
     int32_t launchTiles, orderOffset, orderStride;
     int32_t launchItems;         /* queue positions of this launch: launchTiles, or launchTiles * frameGroups (tile, frame group) items */
     float4* pxCold;              /* per-wave pixel records of this launch: [grid][64 lanes][2] float4 (rt_kernels.h, PX_COLD) */
-    uint32_t* qRecords;          /* queued-stages kernel (experiments/rt_kernels_q.h): per-wave chain records + parked traversal state, [grid][RT_Q_WAVE_DWORDS] */
-    int32_t qFlushMin;           /* traversal lanes hand their results over when this many have finished */
-    int32_t qRefillMin;          /* free traversal lanes are refilled from rayQ when this many are free */
-    int32_t wgTravWaves;         /* workgroup kernel (experiments/rt_kernels_wg.h): traversal waves per eight-wave workgroup */
-    int32_t wgPool;              /* ... and its pool of parked chains (slots) */
-    int32_t qStarveMin;          /* fewer rays than this in and before the traversal lanes: partial batches run */
     int32_t frameGroup;          /* consecutive frames per item (>= 1) */
     int32_t frameGroups;         /* ceil(nFrames / frameGroup) */
     float* staging;              /* nFrames > 1: [frame - frame0][stagingStride pixels] RGBA colours awaiting rt_accumulate_kernel */
@@ -191,10 +158,6 @@ struct KArgs {
     int32_t queueStart;          /* 1: the first position of every wave comes from the queue too (not blockIdx) */
     unsigned long long* tileQueue;
     unsigned long long tileQueueBase;
-    /* EXPERIMENT (RT_XCD_AFFINITY, profiles/r05_ab_layout.txt): eight counters, zero at launch; the queue positions are cut into eight
-     * contiguous ranges and a wave draws from the range of the XCD it runs on (each XCD has its own L2), from the others' when
-     * its own is used up.  Null = one queue for the chip. */
-    unsigned long long* xcdQueues;
     /* longest-chain-first scheduling: queue position -> tile (null = identity), and the
      * per-tile record of the longest pixel chain seen so far (segments in one frame) */
     const uint32_t* tileOrder;

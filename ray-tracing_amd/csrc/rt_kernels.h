@@ -97,14 +97,6 @@ struct Stats {
     /* wave-level phase profile (stats launches only): how often the wave executed a phase
      * and how many lanes were active in it — lane utilisation per phase = lanes / (64 * execs) */
     uint32_t phExec[RT_N_PHASES], phLanes[RT_N_PHASES];
-#ifdef RT_PHASE_TIMES
-    /* measurement build only: elapsed time (s_memtime ticks) between the marks of the COARSE phases — loop top, refill, camera
-     * ray, spheres + filter, the whole traverse() call, sky, shade, glass; what follows a mark up to the next one is charged
-     * to it (frame end -> loop, roulette / path end -> the shading phase before it) */
-    uint64_t phT[RT_N_PHASES];
-    uint64_t tPrev;
-    int phPrev;
-#endif
 };
 enum { PH_LOOP = 0, PH_RAYGEN, PH_SPHERES, PH_TRAVERSE_CALL, PH_MODEL, PH_INNER, PH_TRI, PH_SHADE_HIT, PH_SKY, PH_SPHERE_ROOTS, PH_GLASS, PH_REFILL };
 template <bool STATS>
@@ -114,17 +106,6 @@ __device__ __forceinline__ void phase_mark(Stats& st, int ph)
         const unsigned long long m = __ballot(1);
         st.phLanes[ph]++;
         if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) st.phExec[ph]++;
-#ifdef RT_PHASE_TIMES
-        if (ph != PH_MODEL && ph != PH_INNER && ph != PH_TRI && ph != PH_SPHERE_ROOTS) {
-            __builtin_amdgcn_sched_barrier(0); /* the timestamp stays where the mark is: nothing is scheduled across it */
-            const uint64_t now = __builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): the time is the time of the mark, not of its first use */
-            __builtin_amdgcn_sched_barrier(0);
-            if (st.phPrev >= 0) st.phT[st.phPrev] += now - st.tPrev;
-            st.tPrev = now;
-            st.phPrev = ph;
-        }
-#endif
     }
 }
 
@@ -132,13 +113,8 @@ __device__ __forceinline__ void phase_mark(Stats& st, int ph)
 __device__ __forceinline__ float rand_normal(uint32_t* state)
 {
     float theta = 2 * 3.1415926f * rt_random_value(state);
-#ifdef RT_FAST_TRANS_CEILING /* measurement only (NOT bit-exact): what hardware log / cos would buy — the ceiling of any cheaper contract */
-    float rho = __builtin_sqrtf(-2 * __logf(rt_random_value(state)));
-    return rho * __cosf(theta);
-#else
     float rho = rt_sqrt(-2 * rt_log(rt_random_value(state)));
     return rho * rt_cos(theta);
-#endif
 }
 __device__ __forceinline__ rt_f3 rand_direction(uint32_t* state)
 {
@@ -224,19 +200,6 @@ __device__ __forceinline__ rt_f3 material_colour(const DMaterial& mat, rt_f3 pos
     return rt_lerp3(col, rt_v3(mat.specularCol[0], mat.specularCol[1], mat.specularCol[2]), isSpecular ? 1.0f : 0.0f);
 }
 
-/* EXPERIMENT (make tri-nt): triangle records are the least re-used lines of a BVH scene — fetched with the non-temporal
- * policy they are the first an L2 gives up, which leaves the room to node pairs (profiles/r05_ab_layout.txt) */
-#ifdef RT_TRI_NT
-typedef float rt_nt4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 rt_load_nt(const float4* p)
-{
-    const rt_nt4 v = __builtin_nontemporal_load(reinterpret_cast<const rt_nt4*>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-#define RT_TRI_LOAD(q, p, i) const float4 q = rt_load_nt((p) + (i))
-#else
-#define RT_TRI_LOAD(q, p, i) const float4 q = (p)[i]
-#endif
 /* RayTriangle — RC:188-215 on a pre-differenced triangle. Updates the closest
  * hit with the reference's strict '<' (RC:256). */
 __device__ __forceinline__ void tri_test(const DTri* __restrict__ tris, int triUnit, rt_f3 pos, rt_f3 dir, bool cull,
@@ -246,7 +209,7 @@ __device__ __forceinline__ void tri_test(const DTri* __restrict__ tris, int triU
      * decides where the runs of a leaf lie): a 32-bit byte offset from the uniform array base (SGPR base + VGPR offset
      * addressing, see the inner step) is one shift; rt_upload_scene refuses scenes whose triangle space reaches 4 GiB */
     const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tris) + ((uint32_t)triUnit << 4));
-    RT_TRI_LOAD(q0, p, 0); RT_TRI_LOAD(q1, p, 1); RT_TRI_LOAD(q2, p, 2);
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2];
     rt_f3 A = rt_v3(q0.x, q0.y, q0.z);
     rt_f3 edgeAB = rt_v3(q0.w, q1.x, q1.y);
     rt_f3 edgeAC = rt_v3(q1.z, q1.w, q2.x);
@@ -443,17 +406,11 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
             }
             return keep;
         };
-#ifdef RT_NO_PACKED_FILTER /* A/B build (make EXTRA=-DRT_NO_PACKED_FILTER): one model per step */
-        if (!MANY) {
-            for (int m = 0; m < nf; m++) cand |= (test_model(m) ? 1ull : 0ull) << m;
-        } else if (false) {
-#else
         unsigned long long scalarCand = 0;
         if (!MANY && STATS) { /* up to 64 models: the one-model-per-step loop for the exact counters and the audits ... */
             for (int m = 0; m < nf; m++) scalarCand |= (test_model(m) ? 1ull : 0ull) << m;
         }
         if (!MANY) { /* ... and the packed loop that SHIPS decides the candidates in both builds (the stats build audits it too) */
-#endif
             /* The shipped form of the same loop, TWO models per step (round 4): the boxes sit in SGPRs, and a VALU instruction
              * with an SGPR source issues at the slow rate on gfx950 while v_pk_add/mul_f32 take an SGPR PAIR for the price of one
              * (the two-spheres-per-step pre-test above, profiles/r03_valu_op_rates.txt).  The pair records (rt_context.hip,
@@ -491,9 +448,7 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
                 const bool keep1 = (m + 1 < nf) && keep_of(t0x.y, t1x.y, t0y.y, t1y.y, t0z.y, t1z.y, __float_as_uint(q[13]));
                 cand |= ((keep0 ? 1ull : 0ull) << m) | ((keep1 ? 1ull : 0ull) << (m + 1));
             }
-#ifndef RT_NO_PACKED_FILTER
             if (STATS && (scalarCand & ~cand)) st.filterViolations += (uint32_t)__popcll(scalarCand & ~cand);
-#endif
         } else {
             /* more than 64 models: chunk boxes first (a chunk no lane of the wave hits costs one box test instead of
              * 16), candidates beyond model 62 go to the lane's LDS extension words */
@@ -555,19 +510,14 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
  * single, wave-uniform exit (finished lanes park in RT_CODE_DONE instead of leaving one by
  * one), which keeps the loop-carried state in one set of registers. */
 template <bool STATS, bool SUSPEND, bool MANY>
-__device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, uint32_t* extBase, SceneHit& h, Trav& t, Stats& st,
-                                         const int keepAboveArg = -1)
+__device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, uint32_t* extBase, SceneHit& h, Trav& t, Stats& st)
 {
-#ifdef RT_LDS_NODE_FETCH
-    /* 4 KB slab after [stack][pixel fields][mask extension]; wave-uniform address */
-    uint32_t* const nodeSlab = (extBase - (threadIdx.x & 63)) + (a.extWords ? 2 + a.extWords : 0) * RT_WAVE;
-#endif
     const DModel* __restrict__ models = a.models;
     const DPair* __restrict__ pairs = a.pairs;
     const DTri* __restrict__ tris = a.tris;
     /* the loop runs while more than keepAbove lanes are still traversing: entered * a.suspendNum / RT_SUSPEND_DEN (3/8 unless the
-     * launch tuner found 4/8 faster for this scene) — or what the caller says (the queued-stages kernel, experiments/rt_kernels_q.h) */
-    const int enteredNum = keepAboveArg >= 0 ? keepAboveArg * RT_SUSPEND_DEN : SUSPEND ? __popcll(__ballot(1)) * a.suspendNum : 0;
+     * launch tuner found 4/8 faster for this scene) */
+    const int enteredNum = SUSPEND ? __popcll(__ballot(1)) * a.suspendNum : 0;
     phase_mark<STATS>(st, PH_TRAVERSE_CALL);
     /* One kind of work per iteration, chosen for the whole wave: the kind most lanes are
      * waiting for (wave-uniform branch, so only that code is issued).  A lane deep inside
@@ -579,9 +529,6 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
      * of the lanes that entered are still traversing. */
     bool atNext, atLeaf, atInner;
     int nA, nB, nC;
-#ifdef RT_TRAV_WATCHDOG
-    uint32_t watchdog = 0;
-#endif
 #define RT_TRAV_VOTE()                                                                                         \
     do {                                                                                                       \
         /* a lane between models that has no model left is done: no more demand for phase A */              \
@@ -639,170 +586,21 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
             /* a short burst of inner steps per vote won (lanes that reach a leaf or run out of nodes
              * wait for the next vote): 3 measured best — 1 pays a vote per step, "until no lane
              * is at an inner node" (the classic while-while) idles most lanes most of the time */
-#ifdef RT_PAIR_FETCH
-            /* PAIR-COOPERATIVE inner step (round 5).  The BVH kernels are bound by the vector-memory path: 0.83-0.92 L1 accesses per clock
-             * per CU (profiles/r05_memory_path.txt) — a wave64 load costs the TA / L1 one access per group of neighbouring lanes that fall
-             * into one 128-byte line (tools/ubench/vmem_gather.hip), and an inner step is four loads per lane from one 64-byte record: four
-             * accesses per ray.  Here the two lanes of a pair (2m, 2m+1) fetch each node TOGETHER: in round j they both address the record
-             * of the pair's lane j, lane p reading the 32 bytes of child p (rt_device.h: the record is two halves, one child box + code
-             * each) — one access per load for the pair — and lane p does child p's slab test for BOTH rays (the owner's local ray comes
-             * through DPP operands), i.e. two box tests per lane as before.  One distance and one code per child then cross the pair
-             * (four selects + two DPP moves).  Same boxes, same tests, same order of the results: RC:262-282 to the bit. */
-#pragma clang loop unroll(disable)
-            for (int burst = 0; burst < RT_INNER_BURST; burst++) {
-                const bool mine = t.cur < RT_CODE_DONE;
-                /* who works in which round is decided on scalar masks (no VALU): round j runs for the pairs whose lane j is at an inner
-                 * node.  Only lanes that are inside traverse() can help (the others are switched off in EXEC — a pixel without work, a
-                 * lane that is shading): a lane whose partner is absent fetches both halves itself (mLonely; rare: every lane with a
-                 * path re-enters the traversal in the iteration in which it got its ray). */
-                const unsigned long long mMine = __ballot(mine);
-                const unsigned long long mAlive = __ballot(true);
-                const unsigned long long EVEN = 0x5555555555555555ull, ODD = 0xAAAAAAAAAAAAAAAAull;
-                const unsigned long long mBoth = mAlive & (((mAlive & EVEN) << 1) | ((mAlive & ODD) >> 1)); /* lanes whose partner is here too */
-                const unsigned long long mPaired = mMine & mBoth, mLonely = mMine & ~mBoth;
-                const unsigned long long mAct0 = (mPaired & EVEN) | ((mPaired & EVEN) << 1), mAct1 = (mPaired & ODD) | ((mPaired & ODD) >> 1);
-                const bool odd = __builtin_amdgcn_inverse_ballot_w64(ODD);
-                /* quad_perm selectors: the pair's lane 0 / lane 1 / the partner */
-                constexpr int SEL0 = 0xA0 /* [0,0,2,2] */, SEL1 = 0xF5 /* [1,1,3,3] */, SELX = 0xB1 /* [1,0,3,2] */;
-#define RT_DPP_I(v, sel) __builtin_amdgcn_update_dpp(0, (int)(v), sel, 0xf, 0xf, true)
-#define RT_DPP_F(v, sel) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(v)), sel, 0xf, 0xf, true))
-                const uint32_t offMine = (uint32_t)(t.cur << 4);
-                float dstA = RT_INF, dstB = RT_INF;
-                uint32_t codeA = 0u, codeB = 0u;
-                if (__builtin_amdgcn_inverse_ballot_w64(mAct0 | mAct1)) {
-                    const uint32_t halfOff = odd ? 32u : 0u;
-                    float D0 = RT_INF, D1 = RT_INF;
-                    uint32_t C0 = 0u, C1 = 0u;
-#if RT_PAIR_FETCH == 2 /* variant: both rounds' loads first (the second pair in flight while the first box is tested) — 35 spilled VGPRs at the 80-register budget */
-                    float4 lo0, hi0, lo1, hi1; /* written and read under the same masks */
-                    if (__builtin_amdgcn_inverse_ballot_w64(mAct0)) { /* round 0: the node of the pair's lane 0 */
-                        const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pairs) + ((uint32_t)RT_DPP_I(offMine, SEL0) + halfOff));
-                        lo0 = q[0];
-                        hi0 = q[1];
-                    }
-                    if (__builtin_amdgcn_inverse_ballot_w64(mAct1)) { /* round 1: the node of the pair's lane 1 */
-                        const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pairs) + ((uint32_t)RT_DPP_I(offMine, SEL1) + halfOff));
-                        lo1 = q[0];
-                        hi1 = q[1];
-                    }
-#endif
-                    if (__builtin_amdgcn_inverse_ballot_w64(mAct0)) {
-#if RT_PAIR_FETCH != 2
-                        const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pairs) + ((uint32_t)RT_DPP_I(offMine, SEL0) + halfOff));
-                        const float4 lo0 = q[0], hi0 = q[1];
-#endif
-                        const rt_f3 pos = rt_v3(RT_DPP_F(t.lpos.x, SEL0), RT_DPP_F(t.lpos.y, SEL0), RT_DPP_F(t.lpos.z, SEL0));
-                        const rt_f3 inv = rt_v3(RT_DPP_F(t.linv.x, SEL0), RT_DPP_F(t.linv.y, SEL0), RT_DPP_F(t.linv.z, SEL0));
-                        const float bmin[3] = {lo0.x, lo0.y, lo0.z}, bmax[3] = {hi0.x, hi0.y, hi0.z};
-                        D0 = box_dst(pos, inv, bmin, bmax);
-                        C0 = __float_as_uint(lo0.w);
-                    }
-                    if (__builtin_amdgcn_inverse_ballot_w64(mAct1)) {
-#if RT_PAIR_FETCH != 2
-                        const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pairs) + ((uint32_t)RT_DPP_I(offMine, SEL1) + halfOff));
-                        const float4 lo1 = q[0], hi1 = q[1];
-#endif
-                        const rt_f3 pos = rt_v3(RT_DPP_F(t.lpos.x, SEL1), RT_DPP_F(t.lpos.y, SEL1), RT_DPP_F(t.lpos.z, SEL1));
-                        const rt_f3 inv = rt_v3(RT_DPP_F(t.linv.x, SEL1), RT_DPP_F(t.linv.y, SEL1), RT_DPP_F(t.linv.z, SEL1));
-                        const float bmin[3] = {lo1.x, lo1.y, lo1.z}, bmax[3] = {hi1.x, hi1.y, hi1.z};
-                        D1 = box_dst(pos, inv, bmin, bmax);
-                        C1 = __float_as_uint(lo1.w);
-                    }
-                    /* lane p holds child p of both nodes: the result for its own node stays, the other crosses the pair */
-                    const float keepD = odd ? D1 : D0, giveD = odd ? D0 : D1;
-                    const uint32_t keepC = odd ? C1 : C0, giveC = odd ? C0 : C1;
-                    const float gotD = RT_DPP_F(giveD, SELX);
-                    const uint32_t gotC = (uint32_t)RT_DPP_I(giveC, SELX);
-                    dstA = odd ? gotD : keepD;
-                    dstB = odd ? keepD : gotD;
-                    codeA = odd ? gotC : keepC;
-                    codeB = odd ? keepC : gotC;
-                }
-                if (mLonely) { /* wave-uniform and rare: no partner in the traversal, both halves by the lane itself */
-                    if (__builtin_amdgcn_inverse_ballot_w64(mLonely)) {
-                        const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pairs) + offMine);
-                        {
-                            const float4 lo = q[0], hi = q[1];
-                            const float bmin[3] = {lo.x, lo.y, lo.z}, bmax[3] = {hi.x, hi.y, hi.z};
-                            dstA = box_dst(t.lpos, t.linv, bmin, bmax);
-                            codeA = __float_as_uint(lo.w);
-                        }
-                        {
-                            const float4 lo = q[2], hi = q[3];
-                            const float bmin[3] = {lo.x, lo.y, lo.z}, bmax[3] = {hi.x, hi.y, hi.z};
-                            dstB = box_dst(t.lpos, t.linv, bmin, bmax);
-                            codeB = __float_as_uint(lo.w);
-                        }
-                    }
-                }
-                if (mine) { /* ---- B: one inner node, RC:262-282 */
-                    if (STATS && !t.rootStep) st.inner++;
-                    t.rootStep = false;
-                    phase_mark<STATS>(st, PH_INNER);
-                    bool isNearestA = dstA <= dstB;
-                    float dstNear = isNearestA ? dstA : dstB;
-                    float dstFar = isNearestA ? dstB : dstA;
-                    uint32_t codeNear = isNearestA ? codeA : codeB;
-                    uint32_t codeFar = isNearestA ? codeB : codeA;
-                    if (dstNear < h.dst) {
-                        if (dstFar < h.dst) { stackBase[t.sp * RT_WAVE] = codeFar; t.sp++; }
-                        t.cur = codeNear;
-                    } else if (t.sp == 0) {
-                        t.cur = RT_CODE_NEXT_MODEL;
-                    } else {
-                        t.cur = stackBase[(--t.sp) * RT_WAVE];
-                    }
-                }
-#undef RT_DPP_I
-#undef RT_DPP_F
-            }
-#else
 #pragma clang loop unroll(disable)
             for (int burst = 0; burst < RT_INNER_BURST; burst++)
             if (t.cur < RT_CODE_DONE) { /* ---- B: one inner node, RC:262-282 */
                 if (STATS && !t.rootStep) st.inner++;
                 t.rootStep = false;
                 phase_mark<STATS>(st, PH_INNER);
-#ifndef RT_LDS_NODE_FETCH
                 /* an inner code is the 16-byte unit the pair record starts at (rt_device.h; the host's layout decides where
                  * that is): a 32-bit byte offset from the (wave-uniform) array base — the load takes "SGPR base + VGPR offset",
                  * and the 64-bit shift and add of a full pointer (two slow-class VALU instructions per step on gfx950) become
                  * one fast 32-bit shift; rt_upload_scene refuses scenes whose pair space reaches 4 GiB */
                 const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pairs) + (uint32_t)(t.cur << 4));
                 const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3]; /* (loading only the 8 bytes of q3 that are used changes nothing: 9.9) */
-#else
-                /* EXPERIMENT kept reproducible (make lds-fetch; profiles/r02_lds_node_fetch.txt): the north_star's
-                 * "BVH nodes staged through LDS" as the hardware offers it — the node's four 16-B quarters go
-                 * straight from L2 into an LDS slab with global_load_lds_dwordx4 (destination = wave-uniform base +
-                 * lane*16, so the slab is [quarter][lane]) and are read back with ds_read_b128.  Bit-identical,
-                 * measured slower: the kernel is VALU-issue bound (profiles/r02_occupancy_sweep.txt), the fetch is a
-                 * dependent pointer chase with nothing to overlap, and the slab costs 4 KB of LDS per wave. */
-                {
-                    const char* g = reinterpret_cast<const char*>(pairs) + ((size_t)t.cur << 4);
-                    for (int qq = 0; qq < 4; qq++)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 16 * qq),
-                                                         (__attribute__((address_space(3))) void*)(nodeSlab + qq * RT_WAVE * 4), 16, 0, 0);
-                    __builtin_amdgcn_s_waitcnt(0); /* vmcnt(0) lgkmcnt(0) */
-                }
-                const float4* qs = reinterpret_cast<const float4*>(nodeSlab) + (threadIdx.x & 63);
-                const float4 q0 = qs[0], q1 = qs[RT_WAVE], q2 = qs[2 * RT_WAVE], q3 = qs[3 * RT_WAVE];
-#endif
                 float aMin[3] = {q0.x, q0.y, q0.z}, aMax[3] = {q0.w, q1.x, q1.y};
                 float bMin[3] = {q1.z, q1.w, q2.x}, bMax[3] = {q2.y, q2.z, q2.w};
                 uint32_t codeA = __float_as_uint(q3.x), codeB = __float_as_uint(q3.y);
-#ifdef RT_CHILD_PREFETCH
-                /* EXPERIMENT (make child-prefetch): touch one dword of each child's record (the pair of an inner child, the first
-                 * triangle of a leaf child) as soon as the codes are known, so that the line is on its way while the box tests run */
-                {
-                    const uint32_t offA = (codeA & RT_CODE_LEAF) ? (uint32_t)(t.triBase + (int)(codeA & RT_CODE_MAX_INLINE_START)) << 4 : codeA << 4;
-                    const uint32_t offB = (codeB & RT_CODE_LEAF) ? (uint32_t)(t.triBase + (int)(codeB & RT_CODE_MAX_INLINE_START)) << 4 : codeB << 4;
-                    const char* baseA = (codeA & RT_CODE_LEAF) ? reinterpret_cast<const char*>(tris) : reinterpret_cast<const char*>(pairs);
-                    const char* baseB = (codeB & RT_CODE_LEAF) ? reinterpret_cast<const char*>(tris) : reinterpret_cast<const char*>(pairs);
-                    uint32_t ta, tb;
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(ta) : "v"(baseA + offA) : "memory");
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(tb) : "v"(baseB + offB) : "memory");
-                }
-#endif
                 float dstA = box_dst(t.lpos, t.linv, aMin, aMax);
                 float dstB = box_dst(t.lpos, t.linv, bMin, bMax);
                 bool isNearestA = dstA <= dstB;
@@ -821,7 +619,6 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
                     t.cur = stackBase[(--t.sp) * RT_WAVE];
                 }
             }
-#endif
         } else if (atLeaf) { /* ---- C: one leaf, RC:248-261 */
             uint32_t count = (t.cur >> 24) & 0x7fu;
             uint32_t start = t.cur & RT_CODE_MAX_INLINE_START;
@@ -843,9 +640,6 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
             if (t.sp == 0) t.cur = RT_CODE_NEXT_MODEL;
             else t.cur = stackBase[(--t.sp) * RT_WAVE];
         }
-#ifdef RT_TRAV_WATCHDOG /* experiment builds only: a traversal that does not end (a bug in a variant under test) ends wrong instead of hanging the GPU */
-        if (++watchdog > (1u << 18)) { t.cur = RT_CODE_DONE; t.sp = 0; t.cand = 0; }
-#endif
         RT_TRAV_VOTE();
     } while ((nA + nB + nC) * RT_SUSPEND_DEN > enteredNum);
 #undef RT_TRAV_VOTE
@@ -965,11 +759,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
 {
     extern __shared__ uint32_t s_stack[];
     const int lane = threadIdx.x;
-#ifdef RT_GLOBAL_STACK /* EXPERIMENT (make global-stack): the traversal stack in an L2-resident per-wave array instead of LDS — what a pop costs there */
-    uint32_t* stackBase = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(cold_args().pxCold) + (size_t)blockIdx.x * RT_COLD_STRIDE_BYTES + 2 * RT_WAVE * 16) + lane;
-#else
     uint32_t* stackBase = &s_stack[lane];
-#endif
 
     /* Persistent wave: the wave starts on tile blockIdx.x and, whenever lanes run out of
      * work (their pixel is finished), hands them the next unassigned pixels of its current
@@ -996,9 +786,6 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
         }                                                       \
     } while (0)
     bool queueEmpty;
-#ifdef RT_XCD_EXPERIMENT
-    uint32_t xcdEmpty = 0; /* KArgs::xcdQueues: ranges this wave has seen used up */
-#endif
     /* wave-uniform, once per tile: every row of an 8-row tile lies in one strip (stripRows % 8 == 0);
      * cyclic strips: local strip ls is global strip ls*partCount + partIndex */
 #define RT_SET_POOL(c, tile)                                                                              \
@@ -1016,14 +803,6 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
         if (tile < c.launchItems && c.nFrames > 0 && !c.queueStart) {
             const int q0_ = tile;
             RT_ITEM(c, q0_, tile);
-#ifdef RT_TILE_PRIORITY
-            if (c.tileOrder) {
-                const int T = c.launchTiles;
-                if (tile < (T >> 4)) __builtin_amdgcn_s_setprio(3);
-                else if (tile < (T >> 2)) __builtin_amdgcn_s_setprio(2);
-                else if (tile < (T >> 1)) __builtin_amdgcn_s_setprio(1);
-            }
-#endif
             tile = tile * c.orderStride + c.orderOffset;
             if (c.tileOrder) tile = (int)c.tileOrder[tile];
             RT_SET_POOL(c, tile);
@@ -1065,9 +844,6 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
     t.cand = 0; t.rootStep = false; t.m = 0; t.cur = RT_CODE_NEXT_MODEL; t.sp = 0; t.lpos = t.ldir = t.linv = rt_v3s(0.0f); t.triBase = 0; t.cull = true;
     uint32_t segments = 0;
     Stats st = {};
-#ifdef RT_PHASE_TIMES
-    st.phPrev = -1;
-#endif
 
     for (;;) {
         /* ---- hand pixels to idle lanes (every lane of the wave is active here) */
@@ -1077,26 +853,6 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
             if (poolPos >= 64) {
                 if (queueEmpty) break;
                 int next = 0;
-#ifdef RT_XCD_EXPERIMENT
-                if (c.xcdQueues) { /* EXPERIMENT (make xcd; KArgs::xcdQueues): the range of this wave's XCD first, then the others' */
-                    int got = c.launchItems;
-                    uint32_t emptyNow = xcdEmpty;
-                    if (lane == 0) {
-                        uint32_t xcc;
-                        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                        for (int k = 0; k < 8 && got == c.launchItems; k++) {
-                            const int r = (int)((xcc + (uint32_t)k) & 7u);
-                            if ((emptyNow >> r) & 1u) continue;
-                            const long long lo = (long long)c.launchItems * r / 8, hi = (long long)c.launchItems * (r + 1) / 8;
-                            const unsigned long long pos = atomicAdd(c.xcdQueues + r, 1ull);
-                            if ((long long)pos < hi - lo) got = (int)(lo + (long long)pos);
-                            else emptyNow |= 1u << r;
-                        }
-                    }
-                    next = __builtin_amdgcn_readfirstlane(got);
-                    xcdEmpty = __builtin_amdgcn_readfirstlane(emptyNow);
-                } else
-#endif
                 {
                     if (lane == 0) next = (int)(atomicAdd(c.tileQueue, 1ull) - c.tileQueueBase);
                     next = __builtin_amdgcn_readfirstlane(next);
@@ -1106,28 +862,11 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     const int q_ = next;
                     RT_ITEM(c, q_, next);
                 }
-#ifdef RT_TILE_PRIORITY
-                /* EXPERIMENT (-DRT_TILE_PRIORITY; measured within +-3 % of the shipped kernel on configs 2/3/5, whole
-                 * image and 1/8 partitions, so not enabled): a launch cannot end before its longest pixel chains do, and a chain advances one
-                 * iteration per turn its wave gets on the SIMD.  With the learnt longest-chain-first order the queue
-                 * position says how long the tile's chains are: waves working on the longest ones get issue priority. */
-                if (c.tileOrder) {
-                    const int q = next, T = c.launchTiles;
-                    if (q < (T >> 4)) __builtin_amdgcn_s_setprio(3);
-                    else if (q < (T >> 2)) __builtin_amdgcn_s_setprio(2);
-                    else if (q < (T >> 1)) __builtin_amdgcn_s_setprio(1);
-                    else __builtin_amdgcn_s_setprio(0);
-                }
-#endif
                 next = next * c.orderStride + c.orderOffset;
                 if (c.tileOrder) next = (int)c.tileOrder[next];
                 RT_SET_POOL(c, next);
             }
-#ifdef RT_COHERENT_EXPERIMENT /* measurement build only (make coherent): see KArgs::debugCoherent */
-            const int rank = c.debugCoherent ? 0 : __popcll(idle & ((1ull << lane) - 1ull));
-#else
             const int rank = __popcll(idle & ((1ull << lane) - 1ull));
-#endif
             const int avail = 64 - poolPos;
             if (laneDone && rank < avail) {
                 phase_mark<STATS>(st, PH_REFILL);
@@ -1160,11 +899,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     laneDone = false;
                 }
             }
-#ifdef RT_COHERENT_EXPERIMENT
-            const int wanted = c.debugCoherent ? 1 : __popcll(idle);
-#else
             const int wanted = __popcll(idle);
-#endif
             poolPos += wanted < avail ? wanted : avail;
             idle = __ballot(laneDone);
         }
@@ -1381,9 +1116,6 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
             if (lane == 0) {
                 atomicAdd(slot + 8 + 2 * p, (unsigned long long)e);
                 atomicAdd(slot + 9 + 2 * p, (unsigned long long)l);
-#ifdef RT_PHASE_TIMES
-                atomicAdd(slot + 8 + 2 * RT_N_PHASES + p, (unsigned long long)st.phT[p]); /* wave-uniform: lane 0's copy */
-#endif
             }
         }
     } else if (lane == 0) {

@@ -181,15 +181,28 @@ def test_bench_defaults_and_flags():
     assert args["--scaling"] == "strong"
 
 
-def test_round5_spinup_is_reported_and_switchable():
-    """The device spin-up (profiles/r05_clock_ramp.txt) is part of the line — frames, time, target — and --spinup-ms 0 turns it off; the A/B lines of the
-    final build are kept (on: 48 frames in 40 ms; off: 0 frames) and the steps / warm-up of the line stay the driver's."""
+def test_round6_no_hidden_spinup_and_regions_are_collective():
+    """the wall-clock-bounded spin-up is gone (ranks rendered different frame counts); `value` is the driver's W + K
+    contract with first timed Frame = W + 1, asserted across ranks; the extra regions are sized from an all-reduced time; an incomplete
+    gathered image is a diagnostic (the run fails).  The round-5 A/B lines stay as history."""
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert '"--spinup-ms"' in src and '"spinup": dict(spinup' in src and "accumulated[0] += spinup[\"frames\"]" in src
+    assert "--spinup-ms" not in src and "spinup[" not in src
+    assert '"--regions"' in src and "value_median_of_regions" in src
+    assert "first_frame != 1 + args.warmup" in src and "dist.all_gather_object(firsts, first_frame)" in src
+    assert "gathered image incomplete" in src
+    # the steps of a region come from the job's (all-reduced) elapsed time, never from a rank's own clock
+    body = src[src.index("regions = None"):src.index("# ---- the same K frames through the host mirror")]
+    assert "dist.all_reduce(tt, op=dist.ReduceOp.MAX)" in body and "per_step = max(job_elapsed / args.steps" in body
+    assert "time.perf_counter() - t_spin" not in src
     on = load(os.path.join(ROOT, "profiles", "r05_bench_n1_k20.json"))
-    assert on["steps"] == 20 and on["warmup"] == 5 and on["spinup"]["frames"] >= 4 and on["spinup"]["ms"] >= on["spinup"]["target_ms"] == 40.0
-    assert on["config"]["first_timed_frame"] == 1 + on["spinup"]["frames"] + on["warmup"]      # the reference counts frames from 1 (RCM:71)
-    offs = [load(p) for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_spinup_ab_k20_off_*.json")))]
-    assert len(offs) == 2 and all(o["spinup"]["frames"] == 0 and o["steps"] == 20 and o["warmup"] == 5 for o in offs)
-    assert all(o["config"]["first_timed_frame"] == 1 + 5 for o in offs)
-    assert os.path.exists(os.path.join(ROOT, "profiles", "r05_clock_ramp.txt"))
+    assert on["spinup"]["frames"] >= 4      # round 5's line, kept: what the like-for-like series must NOT be compared with
+    r06 = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06_bench_n1*.json")))
+    for path in r06:
+        d = load(path)
+        assert "spinup" not in d and d["config"]["first_timed_frame"] == 1 + d["warmup"]
+        g = d["regions"]
+        assert g["n"] >= 7 and g["steps_each"] >= d["steps"] and len(g["values"]) == g["n"]
+        assert g["min"] <= d["value_median_of_regions"] <= g["max"]
+        assert g["ms_per_step_median"] * g["steps_each"] >= 45.0          # regions of >= 50 ms (timer slack)
+        if "cpu_baseline" in d:
+            assert d["cpu_baseline"]["kind"] in ("reference", "reference+S1") and d["cpu_baseline_port"]["kind"] == "port"

@@ -45,8 +45,9 @@ def test_partitioned_contexts_bound_targets_and_gather_on_the_gpu(world, cfg):
     assert "DIST_GPU_OK" in p.stdout
 
 
-def _bench(world, *extra, one_device=True):
+def _bench(world, *extra, one_device=True, env_extra=None):
     env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(env_extra or {})
     if one_device:
         env.update(RT_BENCH_ONE_DEVICE="1", RT_BENCH_BACKEND="gloo")
     else:
@@ -90,10 +91,25 @@ def test_bench_spawns_its_own_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_ranks_stay_on_the_same_frames_under_skew():
+    """round 5's wall-clock-bounded spin-up let ranks render different numbers of untimed frames (48 vs 52 on the
+    driver's box), so they timed different Frame indices and the gathered image mixed frame sets.  Nothing in bench.py may depend on a
+    rank's own clock: odd ranks are held back 25 ms before every pass (RT_BENCH_RANK_SKEW_MS) and the line must still prove that every
+    rank rendered the same frames — alpha == frames everywhere, first timed Frame = W + 1, the regions' steps equal on all ranks."""
+    d = _bench(2, "--steps", "3", "--warmup", "2", "--regions", "3", "--region-ms", "8", env_extra={"RT_BENCH_RANK_SKEW_MS": "25"})
+    _check_multi_rank_line(d, 2, 3, [1920, 1080])
+    assert d["config"]["first_timed_frame"] == 3 and "spinup" not in d
+    g = d["regions"]
+    assert g["n"] == 3 and g["steps_each"] >= 3 and g["first_frame"] == 3 + 3 and len(g["values"]) == 3 and min(g["values"]) > 0
+    # every frame of every pass is in the gathered image: W + K + regions + RenderFrame pass + stats replay + batched replay
+    assert d["gathered_image"]["alpha_expected"] == 2 + 3 + 3 * g["steps_each"] + 3 * 3
+
+
+@pytest.mark.gpu
 def test_bench_eight_ranks_on_the_north_star_workload():
     """BASELINE.json configs[4] as the driver's 8-GPU run executes it (3840x2160, 12 bounces, 983k triangles, image
     row-tiled over 8 ranks), reduced to 2 steps, the 8 ranks sharing this box's GPU."""
-    d = _bench(8, "--config", "5", "--steps", "2", "--warmup", "1", "--no-batched")
+    d = _bench(8, "--config", "5", "--steps", "2", "--warmup", "1", "--no-batched", "--regions", "1", "--region-ms", "1")
     _check_multi_rank_line(d, 8, 2, [3840, 2160])
 
 
