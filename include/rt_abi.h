@@ -388,7 +388,14 @@ int rt_camera_view_params(float fov_deg, float aspect, float focus_distance, flo
  * nccl_comm = a caller-owned ncclComm_t whose user rank / size are the context's partition index / count (checked).
  * use_accumulated 1 = AccumulatedRender, 0 = FrameRender.  Synchronous: returns when the image (root) / the send (others)
  * has completed.  RCCL (librccl.so) is loaded on first use; the library has no link-time dependency on it — without RCCL
- * the call fails with RT_ERR_STATE and everything else works. */
+ * the call fails with RT_ERR_STATE and everything else works.
+ * COLLECTIVE — HAZARD: every rank of the communicator must make this call, and a rank that returns early leaves its peers blocked
+ * inside ncclSend / ncclRecv.  What can differ per rank is therefore kept out of the way of the exchange: a root whose d_rgba / bytes
+ * are wrong still RECEIVES every tile (into scratch) and reports RT_ERR_INVALID_ARG after the group has completed, so the senders
+ * return normally.  Errors that every rank sees alike (null communicator, communicator != partition, root out of range, no image
+ * size) return before the exchange on all of them.  Two failures remain one-sided and are the caller's to recover from with
+ * ncclCommAbort on the peers: pending frames that fail to launch on one rank, and a root that cannot allocate its H*W*16-byte
+ * staging area. */
 int rt_gather_rccl(RtContext* ctx, void* nccl_comm, int root, int use_accumulated, void* d_rgba, size_t bytes);
 
 /* ---- test hooks: the kernel's device functions on caller-supplied inputs ---- */

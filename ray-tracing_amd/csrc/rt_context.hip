@@ -87,6 +87,9 @@ struct RtContext {
     int nSpheres = 0, nModels = 0, nTris = 0, nPairs = 0;
     bool flatScene = false; /* every model root is a leaf: the FLAT kernel variant applies */
     int stackEntries = 1; /* deepest BVH of the scene = most entries a lane can push */
+    int wavesPerGroup = 1; /* the BVH variants' workgroups: waves that share one LDS top-of-tree cache (plan_groups) */
+    uint32_t hotUnits = 0; /* units [0, hotUnits) of the pair space are that cache's records */
+    uint32_t travLimit = 1u << 20; /* traversal watchdog (rt_kernels.h, traverse): 64 x the steps one ray can take in this scene */
     bool haveScene = false;
     /* scene (host mirrors needed by rt_update_models) */
     std::vector<RtModel> hModels;
@@ -990,7 +993,45 @@ struct PreparedScene {
     std::vector<RtSphere> hSpheres;
     int nTris = 0, maxHeight = 1;
     bool flat = true;
+    int wavesPerGroup = 1; /* plan_groups: what the layout's cache prefix was sized for */
 };
+
+/* ---- the BVH trace kernels' workgroups (round 6).  A CU keeps 4 x RT_MIN_WAVES_PER_SIMD waves of them (VGPR bound) if the LDS allows:
+ * a wave needs (stack + pixel fields + mask extension) x 256 B.  What the CU's 160 KB leave over becomes the top-of-tree cache — one copy
+ * per WORKGROUP, so the fewer, larger workgroups the more records it holds: 12 waves (2 groups per CU) unless RT_WAVES_PER_GROUP says
+ * otherwise.  Pure arithmetic on the scene's tree height and model count (no device query): every context, the multi-device upload and
+ * rt_debug_layout agree on it.  choose_variant confirms the occupancy with the runtime's own query. */
+#define RT_LDS_BYTES_PER_CU (160 * 1024)
+struct GroupPlan { int wavesPerGroup = 1; int cacheRecords = 0; };
+static size_t wave_lds_bytes(int stackEntries, int extWords)
+{
+    return (size_t)(stackEntries + RT_PIXEL_FIELDS + (extWords ? 2 + extWords : 0)) * RT_WAVE * sizeof(uint32_t);
+}
+static GroupPlan plan_groups(int maxHeight, int nModels)
+{
+    GroupPlan g;
+    const int nf = nModels <= 64 ? 0 : (nModels < 63 + 32 * 32 ? nModels : 63 + 32 * 32); /* make_chunks: extWords */
+    const int extWords = nf ? (nf - 63 + 31) / 32 : 0;
+    const size_t waveBytes = wave_lds_bytes(maxHeight, extWords);
+    int wavesPerCU = 4 * RT_MIN_WAVES_PER_SIMD;
+    if ((size_t)wavesPerCU * waveBytes > RT_LDS_BYTES_PER_CU) wavesPerCU = (int)(RT_LDS_BYTES_PER_CU / waveBytes);
+    if (wavesPerCU < 1) return g;
+    int want = RT_MAX_WAVES_PER_GROUP;
+    if (const char* e = getenv("RT_WAVES_PER_GROUP")) want = atoi(e);
+    if (want < 1) want = 1;
+    if (want > RT_MAX_WAVES_PER_GROUP) want = RT_MAX_WAVES_PER_GROUP;
+    while (want > 1 && wavesPerCU % want) want--; /* whole groups fill the CU's wave slots */
+    const int groupsPerCU = wavesPerCU / want;
+    /* LDS is handed out in blocks: keep 1 KB per group clear of the nominal share */
+    const long long share = (long long)RT_LDS_BYTES_PER_CU / groupsPerCU - 1024 - (long long)want * (long long)waveBytes;
+    long long records = share > 0 ? share / (long long)sizeof(DPair) : 0;
+    if (const char* e = getenv("RT_HOT_KB")) { const long long cap = atoll(e) * 1024 / (long long)sizeof(DPair); if (cap < records) records = cap < 0 ? 0 : cap; }
+    if (records > (1 << 16)) records = 1 << 16;
+    if (records < 16) return g; /* not worth a workgroup: single-wave groups, no cache */
+    g.wavesPerGroup = want;
+    g.cacheRecords = (int)records;
+    return g;
+}
 
 /* errors are reported on `ctx` (may be any context of the caller) */
 static int prepare_scene(RtContext* ctx, const RtModel* models, int n_models, const RtTriangle* triangles, int n_triangles,
@@ -1138,6 +1179,14 @@ static int prepare_scene(RtContext* ctx, const RtModel* models, int n_models, co
         RtLayout L;
         const char* want = layoutOverride ? layoutOverride : getenv("RT_LAYOUT");
         if (!parse_layout(want ? want : RT_LAYOUT_DEFAULT, &L)) return fail(ctx, RT_ERR_INVALID_ARG, "RT_LAYOUT=%s: unknown layout", want ? want : RT_LAYOUT_DEFAULT);
+        {   /* the top-of-tree cache: as many records as the workgroups' LDS holds (or what RT_LAYOUT's cache=N says, within that) */
+            bool anyInner = false;
+            for (int i = 0; i < n_models; i++) anyInner = anyInner || !(rootCodes[i] & RT_CODE_LEAF);
+            const GroupPlan gp = anyInner ? plan_groups(maxHeight, n_models) : GroupPlan();
+            ps.wavesPerGroup = gp.wavesPerGroup;
+            if (L.cacheRecords < 0 || L.cacheRecords > gp.cacheRecords) L.cacheRecords = gp.cacheRecords;
+            if (L.dense()) L.cacheRecords = 0; /* the dense layout moves nothing */
+        }
         LayoutEngine eng;
         eng.canon = ps.pairs.data();
         eng.nCanon = nPairs;
@@ -1222,6 +1271,15 @@ static int commit_scene(RtContext* ctx, const PreparedScene& ps, const RtContext
     ctx->hTriBase = ps.lay.triBase;
     ctx->stackEntries = ps.maxHeight;
     ctx->flatScene = ps.flat;
+    ctx->hotUnits = ps.flat ? 0u : ps.lay.hotUnits;
+    {   /* one ray, one segment: every model once (a step each), every pair and every leaf of its tree at most once — and the same tree once
+         * per model that uses it.  64 lanes, one step of one lane per iteration at least; the factor 2 is slack, not arithmetic. */
+        const unsigned long long steps = (unsigned long long)ps.hModels.size() * (2ull * ps.nPairs + 2ull) + 16ull;
+        const unsigned long long lim = 2ull * 64ull * steps;
+        ctx->travLimit = lim > 0x7fffffffull ? 0x7fffffffu : (uint32_t)lim;
+        if (const char* e = getenv("RT_TRAV_LIMIT")) ctx->travLimit = (uint32_t)strtoul(e, nullptr, 10); /* test hook: make the watchdog fire */
+    }
+    ctx->wavesPerGroup = ctx->hotUnits ? ps.wavesPerGroup : 1;
     ctx->hModels = ps.hModels;
     ctx->hRootCodes = ps.rootCodes;
     ctx->haveScene = true;
@@ -1494,6 +1552,7 @@ struct LaunchPlan {
     size_t ldsBytes = 0;
     int blockThreads = RT_WAVE;
     int variant = 0;             /* slot of the occupancy cache */
+    int wavesPerGroup = 1;       /* waves of a workgroup: each is one persistent wave of the launch */
     long long resident = 0;      /* workgroups the chip keeps resident */
 };
 
@@ -1600,9 +1659,19 @@ static void other_stream_settled(RtContext* ctx, int s) { ctx->ord.accWriterPend
 static int choose_variant(RtContext* ctx, KArgs& a, LaunchPlan& plan, bool* manyOut)
 {
     const size_t coldBytes = ctx->flatScene ? (size_t)2 * RT_WAVE * 16 : 0; /* the FLAT variant keeps its pixel records in LDS (rt_kernels.h, PX_COLD) */
-    /* traversal stack + pixel fields + (more than 64 models) the mask extension: summary + words + the MANY variant's bounce row */
-    plan.ldsBytes = (size_t)(ctx->stackEntries + RT_PIXEL_FIELDS + (ctx->extWords ? 2 + ctx->extWords : 0)) * RT_WAVE * sizeof(uint32_t) + coldBytes;
+    /* a wave: traversal stack + pixel fields + (more than 64 models) the mask extension: summary + words + the MANY variant's bounce row;
+     * a workgroup of the BVH variants: the top-of-tree cache, then its waves' regions (plan_groups) */
+    const size_t waveBytes = wave_lds_bytes(ctx->stackEntries, ctx->extWords) + coldBytes;
+    const int wpb = ctx->flatScene ? 1 : ctx->wavesPerGroup;
+    const uint32_t hotUnits = ctx->flatScene ? 0u : ctx->hotUnits;
+    plan.wavesPerGroup = wpb;
+    plan.blockThreads = RT_WAVE * wpb;
+    plan.ldsBytes = (size_t)hotUnits * 16 + (size_t)wpb * waveBytes;
+    a.wavesPerGroup = wpb;
+    a.hotUnits = (int32_t)hotUnits;
+    a.waveLdsDwords = (int32_t)(waveBytes / sizeof(uint32_t));
     a.stackEntries = ctx->stackEntries;
+    a.travLimit = ctx->travLimit;
     const bool many = ctx->nChunks > 0 && !ctx->flatScene;
     *manyOut = many;
     plan.kern = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_kernel<true, true> : rtk::rt_trace_kernel<false, true>)
@@ -1614,11 +1683,16 @@ static int choose_variant(RtContext* ctx, KArgs& a, LaunchPlan& plan, bool* many
     plan.variant = (ctx->flatScene ? 2 : many ? 4 : 0) + (ctx->stats ? 1 : 0);
     if (ctx->occBytes[plan.variant] != plan.ldsBytes + 1) { /* occupancy query cached per (variant, LDS bytes) */
         int perCU = 0;
+        if (plan.ldsBytes > 48 * 1024) { /* more dynamic LDS than the default limit of a launch */
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(plan.kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.ldsBytes));
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(plan.kernHalf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.ldsBytes));
+        }
         HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, plan.kern, plan.blockThreads, plan.ldsBytes));
         ctx->occPerCU[plan.variant] = perCU > 0 ? perCU : 1;
         ctx->occBytes[plan.variant] = plan.ldsBytes + 1;
         if (getenv("RT_DEBUG_LAUNCH"))
-            fprintf(stderr, "[rt] kernel variant %d: %d stack entries, %zu B of LDS per workgroup of %d threads, %d workgroups per CU\n", plan.variant, ctx->stackEntries, plan.ldsBytes, plan.blockThreads, perCU);
+            fprintf(stderr, "[rt] kernel variant %d: %d stack entries, %zu B of LDS per workgroup of %d threads (%u B of it the top-of-tree cache: %u records), %d workgroups per CU\n",
+                    plan.variant, ctx->stackEntries, plan.ldsBytes, plan.blockThreads, hotUnits * 16u, hotUnits / 4u, perCU);
     }
     plan.resident = (long long)ctx->occPerCU[plan.variant] * ctx->numCUs;
     return RT_OK;
@@ -1627,7 +1701,8 @@ static int choose_variant(RtContext* ctx, KArgs& a, LaunchPlan& plan, bool* many
 /* ---- prepare buffers: the resident waves' pixel records */
 static int prepare_records(RtContext* ctx, const LaunchPlan& plan)
 {
-    const long long waves = ctx->gridOverride > plan.resident ? ctx->gridOverride : plan.resident;
+    const long long resWaves = plan.resident * plan.wavesPerGroup;
+    const long long waves = (ctx->gridOverride > resWaves ? ctx->gridOverride : resWaves) + plan.wavesPerGroup;
     if (ctx->pxColdWaves < waves) { /* kernels in flight use the old block: freed after a synchronise, not now */
         HIP_TRY(ctx, hipStreamSynchronize(joined(ctx)));
         hipFree(ctx->dPxCold); ctx->dPxCold = nullptr; ctx->pxColdWaves = 0;
@@ -1836,14 +1911,20 @@ static int enqueue_trace(RtContext* ctx, KArgs& a, const LaunchPlan& plan, int t
         if (staged && ctx->flatScene && ctx->params.numRaysPerPixel < 65536) {
             if (ctx->frameGroupOverride > 0) group = ctx->frameGroupOverride;
             else
-                while (group < 4 && 2 * group <= nFrames && (long long)partTiles * ((nFrames + 2 * group - 1) / (2 * group)) >= 8 * plan.resident) group *= 2;
+                while (group < 4 && 2 * group <= nFrames && (long long)partTiles * ((nFrames + 2 * group - 1) / (2 * group)) >= 8 * plan.resident * plan.wavesPerGroup) group *= 2;
             if (group > nFrames) group = nFrames;
         }
         a.frameGroup = group;
         a.frameGroups = staged ? (nFrames + group - 1) / group : 1;
         const long long items = (long long)partTiles * a.frameGroups;
-        int grid = (int)(plan.resident < items ? plan.resident : items);
-        if (ctx->gridOverride > 0) grid = (int)(ctx->gridOverride < items ? ctx->gridOverride : items);
+        /* the grid: workgroups of wavesPerGroup persistent waves each — as many as the chip keeps resident, never more waves than there
+         * are items (rounded up to whole workgroups: a wave without an item of its own goes to the queue, finds it empty and ends) */
+        const int wpb = plan.wavesPerGroup;
+        long long wantWaves = plan.resident * wpb < items ? plan.resident * wpb : items;
+        if (ctx->gridOverride > 0) wantWaves = ctx->gridOverride < items ? ctx->gridOverride : items;
+        const int grid = (int)((wantWaves + wpb - 1) / wpb);
+        const unsigned long long gridWaves = (unsigned long long)grid * wpb;
+        const unsigned long long byIndex = gridWaves < (unsigned long long)items ? gridWaves : (unsigned long long)items; /* positions taken by wave index */
         a.launchTiles = partTiles;
         a.launchItems = (int)items;
         a.orderOffset = p;
@@ -1852,13 +1933,13 @@ static int enqueue_trace(RtContext* ctx, KArgs& a, const LaunchPlan& plan, int t
          * through the queue.  Two kernels sharing the chip: workgroups are dispatched as slots free up, possibly late, so every
          * position — the longest chains first — comes from the queue. */
         a.queueStart = parts == 2 ? 1 : 0;
-        if (ctx->verbose) fprintf(stderr, "[raytrace_hip] launch variant=%d part=%d/%d tiles=%d grid=%d perCU=%d lds=%zu\n", plan.variant, p, parts, partTiles, grid, ctx->occPerCU[plan.variant], plan.ldsBytes);
+        if (ctx->verbose) fprintf(stderr, "[raytrace_hip] launch variant=%d part=%d/%d tiles=%d grid=%d x %d waves perCU=%d lds=%zu\n", plan.variant, p, parts, partTiles, grid, wpb, ctx->occPerCU[plan.variant], plan.ldsBytes);
         /* stream, pixel-record slot and tile-queue counter of this kernel: part p of a two-part frame, or the fused launch's lane */
         const int q = parts == 2 ? p : lane;
         hipStream_t st = LaunchOrder::stream_of(ctx, q);
         a.pxCold = (float4*)((char*)ctx->dPxCold + (size_t)q * ctx->pxColdWaves * RT_COLD_STRIDE_BYTES);
         a.tileQueue = ctx->dTileQueue + q;
-        a.tileQueueBase = ctx->tileQueueNext[q] - (a.queueStart ? 0ull : (unsigned long long)grid);
+        a.tileQueueBase = ctx->tileQueueNext[q] - (a.queueStart ? 0ull : byIndex);
         int rc;
         if ((rc = LaunchOrder::before_order_read(ctx, q))) return rc;
         if (!staged && (rc = LaunchOrder::before_acc_write(ctx, q, parts == 1))) return rc; /* the trace kernel itself adds into the accumulation buffer (RCC:20-23) */
@@ -1868,8 +1949,8 @@ static int enqueue_trace(RtContext* ctx, KArgs& a, const LaunchPlan& plan, int t
         if (probe) { hipEventRecord(probe->stop, st); probe->live = true; }
         HIP_TRY(ctx, hipGetLastError()); /* a refused launch ran no wave: the device counter did not move */
         mark_fused_launch_end(ctx, fuseSlot, st, nFrames);
-        /* every tile not taken by blockIdx is one successful fetch, and each of the grid waves overshoots once */
-        ctx->tileQueueNext[q] += (unsigned long long)items + (a.queueStart ? (unsigned long long)grid : 0ull);
+        /* every position not taken by wave index is one successful fetch, and each of the grid's waves overshoots once */
+        ctx->tileQueueNext[q] += (unsigned long long)items - (a.queueStart ? 0ull : byIndex) + gridWaves;
         if (q == 1) LaunchOrder::side_used(ctx);
         if (!staged && (rc = LaunchOrder::after_acc_write(ctx, q, parts == 1))) return rc;
     }
@@ -2208,8 +2289,8 @@ int rt_get_counters(RtContext* ctx, RtCounters* out)
     out->modelVisits = sum[5];
     out->pixelFrames = ctx->pixelFrames;
     out->gpuMs = ctx->gpuMs;
-    /* slot 7 = a kernel's watchdog (only the workgroup experiment's kernel has one; the product kernels never write it) */
-    if (sum[7]) return fail(ctx, RT_ERR_HIP, "a kernel's watchdog fired in %llu waves (a wave waited too long for the others)", sum[7]);
+    /* slot 7 = the traversal watchdog (rt_kernels.h, traverse): a wave ended its lanes' walks because no validated scene needs that many steps */
+    if (h[7]) return fail(ctx, RT_ERR_HIP, "the traversal watchdog fired %llu times: a walk did not end (scene validation has a hole, or device memory is corrupt); the images since the last rt_reset_counters are not valid", h[7]);
     return RT_OK;
 }
 
@@ -2234,8 +2315,12 @@ int rt_debug_phase_profile(RtContext* ctx, uint64_t* out, int n)
         out[2 * RT_N_PHASES] = 0;
         for (int s = 0; s < RT_COUNTER_SLOTS; s++) out[2 * RT_N_PHASES] += h[(size_t)s * RT_COUNTER_FIELDS + 6];
     }
-    for (int p = 0; p < RT_N_PHASES && 2 * RT_N_PHASES + 1 + p < n; p++) { /* elapsed ticks per coarse phase: measurement build only, else 0 */
+    /* then: inner steps served by the LDS top-of-tree cache; inner steps (lane-steps) taken while >= 48 lanes of the wave stood on ONE node;
+     * the same for >= 3/4 of >= 16 active lanes; the rest 0 */
+    for (int p = 0; p < RT_N_PHASES && 2 * RT_N_PHASES + 1 + p < n; p++) {
         out[2 * RT_N_PHASES + 1 + p] = 0;
+        if (p < 3)
+            for (int s = 0; s < RT_COUNTER_SLOTS; s++) out[2 * RT_N_PHASES + 1 + p] += h[(size_t)s * RT_COUNTER_FIELDS + 8 + 2 * RT_N_PHASES + p];
     }
     return RT_OK;
 }
@@ -2609,7 +2694,9 @@ int rt_gather_rccl(RtContext* ctx, void* nccl_comm, int root, int use_accumulate
     if (root < 0 || root >= world) return fail(ctx, RT_ERR_INVALID_ARG, "rt_gather_rccl: root %d out of range", root);
     const int W = ctx->W, H = ctx->H;
     const bool isRoot = rank == root;
-    if (isRoot && (!d_rgba || bytes != (size_t)W * H * 16)) return fail(ctx, RT_ERR_INVALID_ARG, "rt_gather_rccl: bytes %zu != H*W*16 = %zu", bytes, (size_t)W * H * 16);
+    /* a collective: what only ONE rank can get wrong must not keep it out of the exchange (its peers would block in ncclSend for ever):
+     * a root with a bad destination still receives every tile, and says so afterwards (include/rt_abi.h) */
+    const bool badDst = isRoot && (!d_rgba || bytes != (size_t)W * H * 16);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = joined(ctx);
     const float* src = use_accumulated ? (ctx->boundAccum ? ctx->boundAccum : ctx->ownAccum) : (ctx->boundFrame ? ctx->boundFrame : ctx->ownFrame);
@@ -2641,7 +2728,7 @@ int rt_gather_rccl(RtContext* ctx, void* nccl_comm, int root, int use_accumulate
     const int eEnd = R->GroupEnd();
     if ((rc = check(e, "ncclSend / ncclRecv"))) return rc;
     if ((rc = check(eEnd, "ncclGroupEnd"))) return rc;
-    if (isRoot)
+    if (isRoot && !badDst)
         for (int r = 0; r < world; r++) {
             const int rows = (int)(rowOff[r + 1] - rowOff[r]);
             if (!rows) continue;
@@ -2654,6 +2741,7 @@ int rt_gather_rccl(RtContext* ctx, void* nccl_comm, int root, int use_accumulate
         }
     HIP_TRY(ctx, hipStreamSynchronize(st));
     flush_timer(ctx);
+    if (badDst) return fail(ctx, RT_ERR_INVALID_ARG, "rt_gather_rccl: bytes %zu != H*W*16 = %zu (the tiles were received and dropped)", bytes, (size_t)W * H * 16);
     return RT_OK;
 }
 

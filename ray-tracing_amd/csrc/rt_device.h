@@ -32,9 +32,10 @@
 #define RT_COUNTER_SLOTS 1024        /* counters are spread over slots to avoid same-address atomics */
 #define RT_PIXEL_FIELDS 4
 #define RT_N_PHASES 12
+#define RT_MAX_WAVES_PER_GROUP 12      /* the BVH trace kernels' workgroups: up to 12 waves share one LDS top-of-tree cache (rt_kernels.h) */
 /* bytes of a wave's record in KArgs::pxCold: two float4 per lane (+ the traversal stack in the RT_GLOBAL_STACK experiment) */
 #define RT_COLD_STRIDE_BYTES (2 * RT_WAVE * 16)
-#define RT_COUNTER_FIELDS (8 + 2 * RT_N_PHASES)
+#define RT_COUNTER_FIELDS (8 + 2 * RT_N_PHASES + 4) /* ... + hot-cache steps, node-uniform steps (>= 48 lanes, >= 3/4 of the active lanes) */
 
 /* Every record of the traversal is named by the 16-byte UNIT it starts at (rt_layout.h decides where the records lie):
  * node codes: bit31 = leaf.  leaf: [30:24] = triangle count (1..127), [23:0] = first unit of the leaf's run of DTri records
@@ -130,7 +131,11 @@ struct KArgs {
     int32_t localRows;
     int32_t stripRows, partIndex, partCount;
     int32_t tilesX, tilesY;
-    int32_t stackEntries;        /* LDS: [stackEntries][64] traversal stack, then [RT_PIXEL_FIELDS][64] pixel bookkeeping */
+    int32_t stackEntries;        /* a wave's LDS: [stackEntries][64] traversal stack, then [RT_PIXEL_FIELDS][64] pixel bookkeeping */
+    /* the BVH variants' workgroups (round 6): wavesPerGroup waves, LDS = [hot cache: hotUnits x 16 B][wave 0's region][wave 1's] ...;
+     * units [0, hotUnits) of the pair space are the top-of-tree records the workgroup copies into LDS when it starts (rt_layout.h) */
+    int32_t wavesPerGroup, hotUnits, waveLdsDwords;
+    uint32_t travLimit;          /* traversal watchdog: iterations of one traverse() call no validated scene can reach (rt_kernels.h) */
     /* uniforms (RtParams) */
     int32_t maxBounce, spp, frame0, nFrames, seed, useSky, accumulate;
     float defocus, diverge, sunFocus, sunIntensity;

@@ -64,6 +64,7 @@ namespace rtk {
  * compiler use scalar loads (s_load_dwordx4/x8 into SGPRs) instead of 64
  * identical vector loads. */
 #define RT_CAS __attribute__((address_space(4)))
+#define RT_LDS __attribute__((address_space(3)))
 
 /* v_min_f32 / v_max_f32 (IEEE minNum/maxNum: a NaN operand yields the other one,
  * like HLSL).  They may differ from rt_min/rt_max only in the sign of a zero
@@ -94,6 +95,8 @@ struct SceneHit {
 
 struct Stats {
     uint32_t inner, leaf, tri, sphere, model, filterViolations;
+    uint32_t hotSteps; /* inner steps served by the LDS top-of-tree cache */
+    uint32_t uni48, uniMaj; /* lane-steps of inner steps in which >= 48 lanes / >= 3/4 of >= 16 active lanes stand on one node */
     /* wave-level phase profile (stats launches only): how often the wave executed a phase
      * and how many lanes were active in it — lane utilisation per phase = lanes / (64 * execs) */
     uint32_t phExec[RT_N_PHASES], phLanes[RT_N_PHASES];
@@ -510,7 +513,8 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
  * single, wave-uniform exit (finished lanes park in RT_CODE_DONE instead of leaving one by
  * one), which keeps the loop-carried state in one set of registers. */
 template <bool STATS, bool SUSPEND, bool MANY>
-__device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, uint32_t* extBase, SceneHit& h, Trav& t, Stats& st)
+__device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, uint32_t* extBase, SceneHit& h, Trav& t, Stats& st,
+                                         const RT_LDS char* hotLds, const uint32_t hotUnits)
 {
     const DModel* __restrict__ models = a.models;
     const DPair* __restrict__ pairs = a.pairs;
@@ -529,6 +533,14 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
      * of the lanes that entered are still traversing. */
     bool atNext, atLeaf, atInner;
     int nA, nB, nC;
+    /* WATCHDOG (round 6).  The reference walks nodeOffset + startIndex with no bounds or cycle check (RC:245-252, 264-267); here
+     * rt_upload_scene refuses every buffer that could make a walk endless (cycles, depth > 32, indices out of range), so this never fires
+     * — but a traversal that does not end would occupy a shared GPU until the driver resets it, and validation is code like any other.
+     * Every iteration of the loop below advances at least one lane by one step, and a lane has at most travSteps steps in a scene
+     * (every model's pairs and leaves once): more than 64 x travSteps iterations in ONE call cannot happen on validated buffers.  A wave
+     * that gets there ends its lanes' walks where they are and raises counter slot 7: rt_get_counters / rt_read_* then FAIL (the image
+     * is wrong by then, the device is not lost).  Wave-uniform: one scalar add and compare per vote. */
+    uint32_t watchdog = 0;
 #define RT_TRAV_VOTE()                                                                                         \
     do {                                                                                                       \
         /* a lane between models that has no model left is done: no more demand for phase A */              \
@@ -595,9 +607,43 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
                 /* an inner code is the 16-byte unit the pair record starts at (rt_device.h; the host's layout decides where
                  * that is): a 32-bit byte offset from the (wave-uniform) array base — the load takes "SGPR base + VGPR offset",
                  * and the 64-bit shift and add of a full pointer (two slow-class VALU instructions per step on gfx950) become
-                 * one fast 32-bit shift; rt_upload_scene refuses scenes whose pair space reaches 4 GiB */
-                const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pairs) + (uint32_t)(t.cur << 4));
-                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3]; /* (loading only the 8 bytes of q3 that are used changes nothing: 9.9) */
+                 * one fast 32-bit shift; rt_upload_scene refuses scenes whose pair space reaches 4 GiB.
+                 * TOP-OF-TREE CACHE (round 6): the layout puts the records a ray is most likely to need — the top of every tree,
+                 * ranked by world-space surface area (rt_layout.h, hot set) — at units [0, hotUnits) of the pair space, and the
+                 * workgroup copied exactly those into LDS when it started (trace_body).  The BVH kernels are bound by the
+                 * vector-memory path (0.83-0.92 L1 accesses per clock per CU, four per ray and step; profiles/r05_memory_path.txt)
+                 * while the LDS pipe idles: a step whose node is in the cache costs the TA / L1 nothing.  LDS layout
+                 * [quarter][record] (quarter q of record r at byte (q * nHot + r) * 16): the 16 lanes of a ds_read_b128 pass
+                 * spread over 16 bank groups by r instead of 4.  Same bytes either way: RC:262-282 to the bit. */
+                const uint32_t cur = t.cur;
+                typedef float rt_v4f __attribute__((ext_vector_type(4))); /* (a plain vector type: HIP's float4 class cannot be read through an LDS-qualified pointer) */
+                rt_v4f q0, q1, q2, q3;
+                if (cur < hotUnits) {
+                    /* (LDS-typed pointers: with generic ones the optimiser merges the two branches into one select of addresses and
+                     * nine flat loads — measured 35-88 % slower than no cache at all) */
+                    const RT_LDS char* l = hotLds + (cur << 2);
+                    const uint32_t qs = hotUnits << 2; /* bytes between the quarters: nHot * 16 */
+                    q0 = *reinterpret_cast<const RT_LDS rt_v4f*>(l);
+                    q1 = *reinterpret_cast<const RT_LDS rt_v4f*>(l + qs);
+                    q2 = *reinterpret_cast<const RT_LDS rt_v4f*>(l + 2 * qs);
+                    q3 = *reinterpret_cast<const RT_LDS rt_v4f*>(l + 3 * qs);
+                    if (STATS) st.hotSteps++;
+                } else {
+                    const rt_v4f* q = reinterpret_cast<const rt_v4f*>(reinterpret_cast<const char*>(pairs) + (uint32_t)(cur << 4));
+                    q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; /* (loading only the 8 bytes of q3 that are used changes nothing: 9.9) */
+                }
+                if (STATS) { /* how often most of the wave stands on ONE node (the case for a scalar top-of-tree path) */
+                    const unsigned long long act = __ballot(true);
+                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+                    unsigned long long same = __ballot(cur == c0);
+                    if (__popcll(same) < 48 && (act & ~same)) { /* second try: the node of the first lane that is elsewhere */
+                        const int l2 = __ffsll((long long)(act & ~same)) - 1;
+                        const uint32_t c1 = (uint32_t)__shfl((int)cur, l2, 64);
+                        same = __ballot(cur == c1);
+                    }
+                    if (__popcll(same) >= 48) st.uni48++;
+                    if (__popcll(act) >= 16 && 4 * __popcll(same) >= 3 * __popcll(act)) st.uniMaj++;
+                }
                 float aMin[3] = {q0.x, q0.y, q0.z}, aMax[3] = {q0.w, q1.x, q1.y};
                 float bMin[3] = {q1.z, q1.w, q2.x}, bMax[3] = {q2.y, q2.z, q2.w};
                 uint32_t codeA = __float_as_uint(q3.x), codeB = __float_as_uint(q3.y);
@@ -639,6 +685,10 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
             }
             if (t.sp == 0) t.cur = RT_CODE_NEXT_MODEL;
             else t.cur = stackBase[(--t.sp) * RT_WAVE];
+        }
+        if (++watchdog > a.travLimit) { /* wave-uniform */
+            t.cur = RT_CODE_DONE; t.sp = 0; t.cand = 0;
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(a.counters + 7, 1ull);
         }
         RT_TRAV_VOTE();
     } while ((nA + nB + nC) * RT_SUSPEND_DEN > enteredNum);
@@ -692,10 +742,10 @@ __device__ __forceinline__ void intersect_scene(const KArgs& a, rt_f3 rpos, rt_f
     Trav t;
     if (a.nChunks) { /* wave-uniform: more than 64 models */
         begin_intersect<STATS, false, true>(a, rpos, rdir, extBase, h, t, st);
-        traverse<STATS, false, true>(a, rpos, rdir, stackBase, extBase, h, t, st);
+        traverse<STATS, false, true>(a, rpos, rdir, stackBase, extBase, h, t, st, (const RT_LDS char*)nullptr, 0u);
     } else {
         begin_intersect<STATS, false, false>(a, rpos, rdir, extBase, h, t, st);
-        traverse<STATS, false, false>(a, rpos, rdir, stackBase, extBase, h, t, st);
+        traverse<STATS, false, false>(a, rpos, rdir, stackBase, extBase, h, t, st, (const RT_LDS char*)nullptr, 0u);
     }
 }
 
@@ -757,8 +807,24 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 template <bool STATS, bool FLAT, bool MANY>
 __device__ __forceinline__ void trace_body(const KArgs& a)
 {
-    extern __shared__ uint32_t s_stack[];
-    const int lane = threadIdx.x;
+    /* A workgroup is wavesPerGroup waves (1 for the FLAT variant) that share ONE thing: the LDS copy of the top of the scene's trees
+     * (traverse(), phase B).  LDS: [hot cache: hotUnits x 16 B][wave 0: stack, pixel fields, ...][wave 1: ...] ...  After the fill and its
+     * one barrier the waves never meet again: each is the persistent wave of rounds 1-5 with the global wave index gw where blockIdx.x was. */
+    extern __shared__ uint32_t s_lds[];
+    const int lane = threadIdx.x & (RT_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t hotUnits = FLAT ? 0u : (uint32_t)a.hotUnits;
+    const RT_LDS char* const hotLds = (const RT_LDS char*)s_lds;
+    if (!FLAT && hotUnits) {
+        /* unit i = quarter (i & 3) of record (i >> 2): coalesced 16-byte loads of the pair space's first hotUnits units */
+        const float4* src = reinterpret_cast<const float4*>(a.pairs);
+        float4* dst = reinterpret_cast<float4*>(s_lds);
+        const uint32_t nHot = hotUnits >> 2;
+        for (uint32_t i = threadIdx.x; i < hotUnits; i += blockDim.x) dst[(i & 3u) * nHot + (i >> 2)] = src[i];
+        __syncthreads();
+    }
+    uint32_t* const s_stack = s_lds + (FLAT ? 0u : hotUnits * 4u + (uint32_t)wave * (uint32_t)a.waveLdsDwords);
+    const int gw = FLAT ? (int)blockIdx.x : (int)blockIdx.x * a.wavesPerGroup + wave; /* this wave among the launch's waves */
     uint32_t* stackBase = &s_stack[lane];
 
     /* Persistent wave: the wave starts on tile blockIdx.x and, whenever lanes run out of
@@ -799,7 +865,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
     } while (0)
     {
         const RT_CAS KArgs& c = cold_args();
-        int tile = (int)blockIdx.x;
+        int tile = gw;
         if (tile < c.launchItems && c.nFrames > 0 && !c.queueStart) {
             const int q0_ = tile;
             RT_ITEM(c, q0_, tile);
@@ -829,7 +895,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
      * its records live in LDS too ([2][64] float4 after the pixel fields) — no record traffic to memory at all, and the
      * camera-ray phase reads its focus point back at LDS latency. */
 #define PX_COLD(c) (FLAT ? reinterpret_cast<float4*>(__builtin_assume_aligned(pxu - lane + RT_PIXEL_FIELDS * RT_WAVE, 16)) + lane \
-                         : ((c).pxCold + (size_t)blockIdx.x * (RT_COLD_STRIDE_BYTES / 16) + (size_t)lane)) /* [wave][2][lane]: a wave's store covers 1 KB without gaps */
+                         : ((c).pxCold + (size_t)gw * (RT_COLD_STRIDE_BYTES / 16) + (size_t)lane)) /* [wave][2][lane]: a wave's store covers 1 KB without gaps */
 #define PXU(k) pxu[(k) * RT_WAVE]
 #define PXF(k) pxf[(k) * RT_WAVE]
     uint32_t rng = 0;
@@ -1006,7 +1072,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                 if (FLAT) traverse_flat<STATS>(a, rpos, rdir, h, st);
             }
         }
-        if (inTrav && (FLAT || traverse<STATS, true, MANY>(a, rpos, rdir, stackBase, extBase, h, t, st))) {
+        if (inTrav && (FLAT || traverse<STATS, true, MANY>(a, rpos, rdir, stackBase, extBase, h, t, st, hotLds, hotUnits))) {
             inTrav = false;
             /* the rest of one iteration of Trace's bounce loop — RC:488-538 */
             bool endPath = false;
@@ -1096,7 +1162,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
 #undef PX_COLD
     /* exact work counters: one set of atomics per wave, spread over slots */
     uint32_t segSum = wave_sum(segments);
-    unsigned long long* slot = a.counters + (size_t)(blockIdx.x % RT_COUNTER_SLOTS) * RT_COUNTER_FIELDS;
+    unsigned long long* slot = a.counters + (size_t)((uint32_t)gw % RT_COUNTER_SLOTS) * RT_COUNTER_FIELDS;
     if (STATS) {
         uint32_t in = wave_sum(st.inner), lf = wave_sum(st.leaf), tr = wave_sum(st.tri), sp = wave_sum(st.sphere), md = wave_sum(st.model);
         if (lane == 0) {
@@ -1110,6 +1176,12 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
         {
             uint32_t fv = wave_sum(st.filterViolations);
             if (lane == 0 && fv) atomicAdd(slot + 6, (unsigned long long)fv);
+            uint32_t hs = wave_sum(st.hotSteps), u48 = wave_sum(st.uni48), um = wave_sum(st.uniMaj);
+            if (lane == 0) {
+                atomicAdd(slot + 8 + 2 * RT_N_PHASES + 0, (unsigned long long)hs);
+                atomicAdd(slot + 8 + 2 * RT_N_PHASES + 1, (unsigned long long)u48);
+                atomicAdd(slot + 8 + 2 * RT_N_PHASES + 2, (unsigned long long)um);
+            }
         }
         for (int p = 0; p < RT_N_PHASES; p++) {
             uint32_t e = wave_sum(st.phExec[p]), l = wave_sum(st.phLanes[p]);
@@ -1131,12 +1203,12 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
 /* MANY: scenes with more than 64 models (two-level filter, candidate masks extended into LDS) — a separate
  * instantiation so that the common case keeps its registers */
 template <bool STATS, bool FLAT, bool MANY = false>
-__global__ void __launch_bounds__(RT_WAVE, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : MANY ? RT_MIN_WAVES_PER_SIMD_MANY : RT_MIN_WAVES_PER_SIMD) rt_trace_kernel(const KArgs a)
+__global__ void __launch_bounds__(FLAT ? RT_WAVE : RT_WAVE * RT_MAX_WAVES_PER_GROUP, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : MANY ? RT_MIN_WAVES_PER_SIMD_MANY : RT_MIN_WAVES_PER_SIMD) rt_trace_kernel(const KArgs a)
 {
     trace_body<STATS, FLAT, MANY>(a);
 }
 template <bool STATS, bool FLAT, bool MANY = false>
-__global__ void __launch_bounds__(RT_WAVE, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : MANY ? RT_MIN_WAVES_PER_SIMD_MANY : RT_MIN_WAVES_PER_SIMD) rt_trace_half_kernel(const KArgs a)
+__global__ void __launch_bounds__(FLAT ? RT_WAVE : RT_WAVE * RT_MAX_WAVES_PER_GROUP, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : MANY ? RT_MIN_WAVES_PER_SIMD_MANY : RT_MIN_WAVES_PER_SIMD) rt_trace_half_kernel(const KArgs a)
 {
     trace_body<STATS, FLAT, MANY>(a);
 }

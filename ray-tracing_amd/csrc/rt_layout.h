@@ -17,6 +17,11 @@
  *     align     a leaf's run never crosses a 128-byte line it need not cross (padding)
  *     arena     ONE space for pairs and triangles: a pair is followed by the runs of its leaf children
  *     palign    (arena) a pair never straddles a 128-byte line
+ *     cache=N   (round 6) the TOP-OF-TREE CACHE: the N node pairs a ray is most likely to need — chosen greedily from the roots
+ *               down by the world-space surface area of the node they belong to, summed over the models that share the tree —
+ *               lie at units [0, 4N) of the pair space, in front of every instance; the BVH kernels' workgroups copy exactly that
+ *               prefix into LDS (rt_kernels.h, traverse phase B).  cache (no number) / default = as many as the LDS of a
+ *               workgroup has room for (rt_context.hip, plan_groups); cache=0 = none
  * Anything but `dense` needs a regular scene (no node pair shared between meshes, referenced triangles not much more
  * than the triangles there are); an irregular one silently gets `dense`.
  */
@@ -28,6 +33,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
+
+#include <math.h>
 
 #include <algorithm>
 #include <atomic>
@@ -89,6 +96,7 @@ struct RtLayout {
     bool preorder = false;
     int triMode = 0; /* 0 dense, 1 align, 2 arena */
     bool pairAlign = false;
+    int cacheRecords = -1; /* node pairs in the hot prefix of the pair space: -1 = what the workgroups' LDS holds, 0 = none */
     bool dense() const { return hotLevels == 0 && !preorder && triMode == 0; }
     std::string name() const
     {
@@ -100,6 +108,7 @@ struct RtLayout {
         if (triMode == 1) add("align");
         if (triMode == 2) add("arena");
         if (pairAlign) add("palign");
+        if (cacheRecords > 0) add("cache=" + std::to_string(cacheRecords));
         return s;
     }
 };
@@ -107,6 +116,17 @@ struct RtLayout {
 #ifndef RT_LAYOUT_DEFAULT
 #define RT_LAYOUT_DEFAULT "pre,arena"
 #endif
+
+/* a decimal count in [0, max], nothing behind it (atoi read "hot=abc" as 0) */
+static inline bool parse_count(const char* t, long max, int* out)
+{
+    if (!*t) return false;
+    char* end = nullptr;
+    const long v = strtol(t, &end, 10);
+    if (*end || v < 0 || v > max) return false;
+    *out = (int)v;
+    return true;
+}
 
 /* unknown words are an error (returns false): a mistyped A/B run must not silently measure the default */
 static inline bool parse_layout(const char* s, RtLayout* out)
@@ -120,7 +140,9 @@ static inline bool parse_layout(const char* s, RtLayout* out)
         std::string w = str.substr(i, j - i);
         if (w == "" || w == "dense" || w == "post") { }
         else if (w == "pre") L.preorder = true;
-        else if (w.compare(0, 4, "hot=") == 0) { L.hotLevels = atoi(w.c_str() + 4); if (L.hotLevels < 0 || L.hotLevels > 24) return false; }
+        else if (w.compare(0, 4, "hot=") == 0) { if (!parse_count(w.c_str() + 4, 24, &L.hotLevels)) return false; }
+        else if (w == "cache") L.cacheRecords = -1;
+        else if (w.compare(0, 6, "cache=") == 0) { if (!parse_count(w.c_str() + 6, 1 << 16, &L.cacheRecords)) return false; }
         else if (w == "align") L.triMode = 1;
         else if (w == "arena") L.triMode = 2;
         else if (w == "palign") L.pairAlign = true;
@@ -157,6 +179,7 @@ struct LaidOutScene {
     std::vector<uint32_t> rootCodes; /* per model, final */
     std::vector<int32_t> triBase;    /* per model, units */
     RtLayout used;
+    uint32_t hotUnits = 0; /* units [0, hotUnits) of the pair space = the top-of-tree cache's records (4 units each) */
     std::string error;
 };
 
@@ -372,6 +395,7 @@ struct LayoutEngine {
                     if (!(c & RT_CODE_LEAF)) {
                         if (!preclaimed(c)) claim(c);
                         const bool h = is_hot(c);
+                        if ((int)stack.size() > RT_MAX_BVH_DEPTH + 2) { I.irregular = true; break; } /* (convert() bounds the height; a shared pair below the hot block could loop) */
                         stack.push_back({c, 0, h});
                     }
                     continue;
@@ -382,6 +406,7 @@ struct LayoutEngine {
                     if (!(c & RT_CODE_LEAF)) {
                         if (!preclaimed(c)) claim(c);
                         const bool h = is_hot(c);
+                        if ((int)stack.size() > RT_MAX_BVH_DEPTH + 2) { I.irregular = true; break; }
                         stack.push_back({c, 0, h});
                     }
                     continue;
@@ -394,7 +419,6 @@ struct LayoutEngine {
                     if (!arena) leaf_children(p);
                 }
                 stack.pop_back();
-                if ((int)stack.size() > RT_MAX_BVH_DEPTH + 2) I.irregular = true; /* (convert() bounds the height; a shared pair below the hot block could loop) */
             }
         }
         I.pairUnits = pairCur;
@@ -441,9 +465,61 @@ struct LayoutEngine {
         par((int)insts.size(), [&](int k) { lay_instance(L, insts[k], k, owner.get()); });
         RT_LAYOUT_T("walks");
         bool irregular = false;
-        uint64_t pairCur = 0, triCur = 0, placedTris = 0;
+        for (Inst& I : insts) irregular = irregular || I.irregular;
+        /* ---- the top-of-tree cache's records: greedy from the roots down by expected visits.  A node is entered by the rays that hit its box:
+         * under the usual surface-area argument that is proportional to the box's area in WORLD space — 2 (dy dz |c2 x c3| + dx dz |c1 x c3| +
+         * dx dy |c1 x c2|) for a box of extent d under a linear map with columns c — summed over the models that share the tree.  The node's
+         * box is the union of the two child boxes its pair record holds.  A child's area never exceeds its parent's, so the set stays the
+         * connected top of every tree. */
+        std::vector<uint32_t> hot;
+        if (L.cacheRecords > 0 && !irregular) {
+            struct Cand { double w; uint32_t pair; int inst; };
+            auto worse = [](const Cand& a, const Cand& b) { return a.w < b.w || (a.w == b.w && a.pair > b.pair); };
+            std::vector<Cand> heap;
+            std::vector<double> coef(3 * insts.size(), 0.0);
+            for (size_t k = 0; k < insts.size(); k++)
+                for (int m : insts[k].modelsOf) {
+                    const float* M = models[m].localToWorld; /* column-major: columns at 0, 4, 8 */
+                    const double c1[3] = {M[0], M[1], M[2]}, c2[3] = {M[4], M[5], M[6]}, c3[3] = {M[8], M[9], M[10]};
+                    auto crossLen = [](const double* a, const double* b) {
+                        const double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+                        return sqrt(x * x + y * y + z * z);
+                    };
+                    const double kx = crossLen(c2, c3), ky = crossLen(c1, c3), kz = crossLen(c1, c2);
+                    coef[3 * k + 0] += std::isfinite(kx) ? kx : 0.0;
+                    coef[3 * k + 1] += std::isfinite(ky) ? ky : 0.0;
+                    coef[3 * k + 2] += std::isfinite(kz) ? kz : 0.0;
+                }
+            auto weight = [&](uint32_t p, int k) {
+                const DPair& d = canon[p];
+                double e[3];
+                for (int a = 0; a < 3; a++) {
+                    const double lo = d.aMin[a] < d.bMin[a] ? d.aMin[a] : d.bMin[a], hi = d.aMax[a] > d.bMax[a] ? d.aMax[a] : d.bMax[a];
+                    e[a] = hi - lo;
+                    if (!(e[a] >= 0.0) || !std::isfinite(e[a])) e[a] = 0.0;
+                }
+                const double w = e[1] * e[2] * coef[3 * k] + e[0] * e[2] * coef[3 * k + 1] + e[0] * e[1] * coef[3 * k + 2];
+                return std::isfinite(w) ? w : 0.0;
+            };
+            for (size_t k = 0; k < insts.size(); k++)
+                if (!(insts[k].root & RT_CODE_LEAF)) heap.push_back({weight(insts[k].root, (int)k), insts[k].root, (int)k});
+            std::make_heap(heap.begin(), heap.end(), worse);
+            while (!heap.empty() && (int)hot.size() < L.cacheRecords) {
+                std::pop_heap(heap.begin(), heap.end(), worse);
+                const Cand c = heap.back();
+                heap.pop_back();
+                hot.push_back(c.pair);
+                const uint32_t codes[2] = {canon[c.pair].codeA, canon[c.pair].codeB};
+                for (int s2 = 0; s2 < 2; s2++)
+                    if (!(codes[s2] & RT_CODE_LEAF)) {
+                        heap.push_back({weight(codes[s2], c.inst), codes[s2], c.inst});
+                        std::push_heap(heap.begin(), heap.end(), worse);
+                    }
+            }
+        }
+        const uint64_t hotUnits = (uint64_t)hot.size() * RT_PAIR_UNITS;
+        uint64_t pairCur = hotUnits, triCur = 0, placedTris = 0;
         for (Inst& I : insts) {
-            irregular = irregular || I.irregular;
             /* an instance starts on a line (its own padding rules are relative to its start) */
             pairCur = (pairCur + RT_LINE_UNITS - 1) / RT_LINE_UNITS * RT_LINE_UNITS;
             triCur = (triCur + RT_LINE_UNITS - 1) / RT_LINE_UNITS * RT_LINE_UNITS;
@@ -463,6 +539,8 @@ struct LayoutEngine {
         /* final codes: the inline ones in parallel, the oversized leaves afterwards in instance order (a deterministic table) */
         out.arena = arena;
         out.used = L;
+        out.used.cacheRecords = (int)hot.size();
+        out.hotUnits = (uint32_t)hotUnits;
         out.rootCodes.assign(nModels, 0u);
         out.triBase.assign(nModels, 0);
         std::vector<uint32_t> unitOf(nCanon, UINT32_MAX), leafCode(2 * nCanon, 0u);
@@ -486,6 +564,8 @@ struct LayoutEngine {
                 }
             }
         });
+        /* the cache's records live in the prefix; the place the instance walk gave them stays an (unread, zeroed) hole */
+        for (size_t i = 0; i < hot.size(); i++) unitOf[hot[i]] = (uint32_t)(i * RT_PAIR_UNITS);
         for (size_t k = 0; k < insts.size(); k++) {
             Inst& I = insts[k];
             for (size_t n : later[k]) {

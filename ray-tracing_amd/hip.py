@@ -361,8 +361,11 @@ class HipTracer(abi.Tracer):
         self._check(self.api.debug_phase_profile(self.h, out.ctypes.data, len(out)))
         prof = {p: (int(out[2 * i]), int(out[2 * i + 1])) for i, p in enumerate(self.PHASES)}
         prof["filter_violations"] = (int(out[2 * n]), 0)
-        if out[2 * n + 1:].any():   # a `make phase-times` build: elapsed shader-clock ticks per coarse phase, summed over waves
-            prof["elapsed_ticks"] = {p: int(out[2 * n + 1 + i]) for i, p in enumerate(self.PHASES) if out[2 * n + 1 + i]}
+        # round 6: inner steps (lane-steps) served by the LDS top-of-tree cache, and taken while >= 48 lanes / >= 3/4 of >= 16 active lanes
+        # of the wave stood on ONE node (the case for a scalar top-of-tree path)
+        prof["inner_from_lds_cache"] = (int(out[2 * n + 1]), 0)
+        prof["inner_on_one_node_48_lanes"] = (int(out[2 * n + 2]), 0)
+        prof["inner_on_one_node_3_of_4_active"] = (int(out[2 * n + 3]), 0)
         return prof
 
     def debug_math_eval(self, op, x, y=None):

@@ -176,3 +176,88 @@ def test_schedule_independence_at_scale(pkg, api, seed, monkeypatch):
     (a, fa, sa), (b, fb, sb) = out
     assert (a.view(np.uint32) == b.view(np.uint32)).all() and (fa.view(np.uint32) == fb.view(np.uint32)).all()
     assert sa == sb and sa > 0
+
+
+def _corrupt(pkg, api, rng, mgr):
+    """A real scene's buffers with 1-3 node fields overwritten (tools/ref_fuzz_corrupt.py's generator): child indices anywhere inside the
+    buffer, leaf ranges moved or resized, nodes made second parents of other nodes' children.  Returns the buffers if rt_validate_scene
+    ACCEPTS them, else None."""
+    d = mgr.CreateAllMeshData(mgr.models)
+    m, t, n = d["meshInfo"].copy(), d["triangles"].copy(), d["nodes"].copy()
+    for _ in range(int(rng.integers(1, 4))):
+        what = int(rng.integers(0, 4))
+        i = int(rng.integers(0, len(n)))
+        if what == 0:
+            n["startIndex"][i] = int(rng.integers(0, len(n)))
+        elif what == 1 and n["triangleCount"][i] > 0:
+            n["startIndex"][i] = int(rng.integers(0, 40))
+        elif what == 2 and n["triangleCount"][i] > 0:
+            n["triangleCount"][i] = int(rng.integers(1, 9))
+        else:
+            j = int(rng.integers(0, len(n)))
+            n["startIndex"][i], n["triangleCount"][i] = n["startIndex"][j], n["triangleCount"][j]
+    try:
+        api.validate_scene_arrays(m, t, n, mgr._pack_spheres())
+    except pkg.abi.RtError:
+        return None
+    return m, t, n
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("batch", range(6))
+def test_corrupted_but_accepted_scenes_bit_exact(pkg, api, orc, batch):
+    """VERDICT r5, missing 2: what rt_validate_scene ACCEPTS the device must render like the reference, which walks nodeOffset + startIndex
+    with no bounds or cycle check (RayCommon.hlsl:245-252, 264-267).  40 accepted corruptions per batch (240 in all; tools/ref_fuzz_corrupt.py
+    runs thousands of them through the oracle and the reference's text on the CPU): HIP — the shipped and the STATS instantiation —
+    against the oracle, both render targets and the exact counters, bit for bit; where the reference's own text travelled (oracle/_ref/libref.so),
+    against that too.  The traversal watchdog bounds every kernel: a hole in the validation fails this test, it does not hang the GPU."""
+    import __graft_entry__ as graft
+    ref = None
+    try:
+        ref = graft.load_ref()
+    except AssertionError:
+        ref = None
+    rng = np.random.default_rng(7000 + batch)
+    families = [(3, {}), (4, {"subdivisions": 2}), (6, {})]
+    W, H = 48, 27
+    done = refused = it = 0
+    while done < 40 and it < 4000:
+        it += 1
+        cfg, kw = families[it % 3]
+        sc = pkg.scenes.get(cfg, **kw)
+        sc.spheres = []
+        probe = sc.make_manager(None, api, W, H)
+        bufs = _corrupt(pkg, api, rng, probe)
+        if bufs is None:
+            refused += 1
+            continue
+        seed = 100 * batch + it
+        out = []
+        libs = [(api, False), (api, True), (orc, False)] + ([(ref, False)] if ref is not None else [])
+        for lib, stats in libs:
+            tr = lib.create_tracer(0 if lib is api else 4)
+            if stats:
+                tr.enable_stats(True)
+            sc2 = pkg.scenes.get(cfg, **kw)
+            sc2.spheres = []
+            mgr = sc2.make_manager(tr, orc if lib is ref else lib, W, H)
+            mgr.OnEnable(renderSeed=seed)
+            tr.upload_scene(*bufs, mgr._pack_spheres())
+            for _ in range(2):
+                mgr.RenderFrame()
+            c = tr.counters()
+            out.append((tr.read_accumulated(), tr.read_frame(), c))
+            tr.close()
+        want_acc, want_frame, want_c = out[2]
+        for k, (acc, frame, c) in enumerate(out):
+            if k == 2:
+                continue
+            what = f"batch {batch} case {it} (config {cfg}) vs " + ("shipped", "stats", "", "reference text")[k]
+            assert np.array_equal(acc.view(np.uint32), want_acc.view(np.uint32)), what
+            assert np.array_equal(frame.view(np.uint32), want_frame.view(np.uint32)), what
+            assert c["segments"] == want_c["segments"], what
+            if k != 0:
+                for key in ("innerSteps", "leafSteps", "triTests", "modelVisits"):
+                    assert c[key] == want_c[key], (what, key, c[key], want_c[key])
+        done += 1
+    assert done == 40, (done, refused)

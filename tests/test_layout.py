@@ -12,7 +12,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 
 LAYOUTS = ["dense", "pre", "hot=3", "pre,hot=6", "align", "pre,align", "arena", "pre,arena", "pre,arena,palign", "hot=4,arena",
-           "pre,hot=8,arena,palign"]
+           "pre,hot=8,arena,palign", "pre,arena,cache=0", "pre,arena,cache=5", "pre,arena,cache", "cache=33", "hot=3,align,cache=64"]
+
+
+def without_cache(name):
+    """The layout's name minus the cache word: `used` reports the records the top-of-tree cache really holds (cache=N), which is the
+    smaller of the request, the LDS plan and the inner nodes there are."""
+    return ",".join(w for w in name.split(",") if not w.startswith("cache")) or "dense"
+
+
+def cache_records(name):
+    for w in name.split(","):
+        if w.startswith("cache="):
+            return int(w[6:])
+    return 0
 LEAF = 0x80000000
 
 
@@ -101,15 +114,56 @@ def walk_and_check(models, tris, nodes, lay):
     return n_pairs, n_tris
 
 
+def check_cache_prefix(models, nodes, lay):
+    """The top-of-tree cache (round 6): units [0, 4 N) of the pair space hold N DISTINCT node pairs, each reachable from a root, each the
+    child of an earlier one or a root (the set is the connected top of the trees), and no other inner code points below 4 N."""
+    n_hot = cache_records(lay["used"])
+    pair_space = lay["pair_space"]
+    roots = {int(c) for c in lay["root_codes"] if not (int(c) & LEAF)}
+    if n_hot == 0:
+        return
+    assert len(pair_space) >= 64 * n_hot
+    recs = np.frombuffer(pair_space[: 64 * n_hot].tobytes(), dtype=np.uint32).reshape(n_hot, 16)
+    reachable = set(r for r in roots if r < 4 * n_hot)
+    assert reachable, "a cache without any root in it"
+    children_of_hot = set()
+    for i in range(n_hot):
+        for code in (int(recs[i, 12]), int(recs[i, 13])):
+            if not (code & LEAF):
+                children_of_hot.add(code)
+    for i in range(n_hot):
+        unit = 4 * i
+        assert unit in roots or unit in children_of_hot, f"cache record {i} is neither a root nor the child of a cached pair"
+    # every inner code that points into the prefix is either a root code or held by a cached pair: walk the whole scene
+    seen, stack = set(), list(roots)
+    while stack:
+        u = stack.pop()
+        if u in seen:
+            continue
+        seen.add(u)
+        rec = np.frombuffer(pair_space[u * 16: u * 16 + 64].tobytes(), dtype=np.uint32)
+        for code in (int(rec[12]), int(rec[13])):
+            if not (code & LEAF):
+                if code < 4 * n_hot:
+                    assert u < 4 * n_hot, "a pair outside the cache points into it: the set is not the top of the tree"
+                stack.append(code)
+    assert {4 * i for i in range(n_hot)} <= seen
+
+
 @pytest.mark.parametrize("layout", LAYOUTS)
 @pytest.mark.parametrize("cfg", [2, 3, 6, (4, dict(subdivisions=3)), 9])
 def test_layout_visits_the_callers_tree(env, cfg, layout):
     pkg, api = env
     models, tris, nodes = scene_arrays(pkg, api, cfg)
     lay = api.layout_arrays(models, tris, nodes, layout)
-    assert lay["used"] == layout, lay["used"]
+    assert without_cache(lay["used"]) == without_cache(layout), lay["used"]
+    if "cache=" in layout:   # an explicit request is an upper bound
+        assert cache_records(lay["used"]) <= cache_records(layout)
+    if layout == "dense":
+        assert cache_records(lay["used"]) == 0
     n_pairs, n_tris = walk_and_check(models, tris, nodes, lay)
     assert n_tris > 0
+    check_cache_prefix(models, nodes, lay)
     if layout != "dense":  # records that never straddle / spaces that are not larger than padding allows
         total = len(lay["pair_space"]) + (0 if lay["arena"] else len(lay["tri_space"]))
         assert total <= 64 * max(1, n_pairs) * 2 + 48 * len(tris) * 2 + 256
@@ -122,8 +176,9 @@ def test_layout_of_a_forest_prepared_in_parallel(env, layout):
     models, tris, nodes = scene_arrays(pkg, api, (5, dict(subdivisions=4)))
     assert len(nodes) >= 1 << 16
     lay = api.layout_arrays(models, tris, nodes, layout)
-    assert lay["used"] == layout
+    assert without_cache(lay["used"]) == layout
     n_pairs, n_tris = walk_and_check(models, tris, nodes, lay)
+    check_cache_prefix(models, nodes, lay)
     assert n_tris >= len(tris) - 64
     again = api.layout_arrays(models, tris, nodes, layout)   # deterministic whatever the worker threads did
     assert all(np.array_equal(lay[k], again[k]) for k in ("pair_space", "norm_space", "root_codes", "tri_base", "big_leaves"))
@@ -176,7 +231,7 @@ def test_alignment_rules(env):
     pairs, _ = _walk_units(api.layout_arrays(models, tris, nodes, "pre,arena,palign"))
     assert len(pairs) > 100 and all(u % 8 <= 4 for u in pairs)
     # arena: the run of a leaf child starts right behind its pair (or behind the sibling's run)
-    lay = api.layout_arrays(models, tris, nodes, "pre,arena")
+    lay = api.layout_arrays(models, tris, nodes, "pre,arena,cache=0")   # (a cached pair moves to the prefix, its runs stay where they were)
     pair_space, adjacent, total = lay["pair_space"], 0, 0
     base = {int(c): int(b) for c, b in zip(lay["root_codes"], lay["tri_base"])}
     for root, tb in base.items():
@@ -204,6 +259,9 @@ def test_unknown_layout_is_an_error(env):
         api.layout_arrays(models, tris, nodes, "arenas")
     with pytest.raises(pkg.abi.RtError):
         api.layout_arrays(models, tris, nodes, "palign")  # needs arena
+    for bad in ("hot=abc", "hot=", "hot=3x", "cache=-1", "cache=12q", "hot=25"):   # atoi read "hot=abc" as hot=0
+        with pytest.raises(pkg.abi.RtError):
+            api.layout_arrays(models, tris, nodes, bad)
 
 
 def test_shared_nodes_with_other_triangles_fall_back_to_dense(env):
@@ -297,7 +355,8 @@ def test_random_node_graphs_under_every_layout(env, seed):
     models, tris, nodes = _random_forest(pkg, rng, int(rng.integers(1, 5)), share)
     for layout in ("dense", "pre,arena", "arena", "hot=2,align", "pre,hot=3,arena,palign"):
         lay = api.layout_arrays(models, tris, nodes, layout)
-        assert lay["used"] == ("dense" if share == 2 else layout)   # the same nodes under two triangle offsets: irregular
+        assert without_cache(lay["used"]) == ("dense" if share == 2 else layout)   # the same nodes under two triangle offsets: irregular
+        check_cache_prefix(models, nodes, lay)
         n_pairs, n_tris = walk_and_check(models, tris, nodes, lay)
         assert n_tris > 0
 

@@ -45,11 +45,12 @@ if os.environ.get("RT_PHASES"):
         tr.enable_stats(True); tr.reset_counters(); mgr.RenderFrames(nph)
         c = tr.counters(); ph = tr.phase_profile()
         print(f"config {cfg} phase profile ({nph} frame(s) in one launch, {c['segments']} segments):")
-        ticks = ph.pop("elapsed_ticks", None)
-        if ticks:
-            tot = sum(ticks.values())
-            print("   elapsed time per coarse phase (share of the waves' time; a mark's bucket runs to the next coarse mark): "
-                  + "  ".join(f"{k} {v / tot:.3f}" for k, v in ticks.items()))
+        inner_lanes = ph["inner"][1] or 1
+        for key, label in (("inner_from_lds_cache", "inner steps served by the LDS top-of-tree cache"),
+                           ("inner_on_one_node_48_lanes", "inner steps with >= 48 lanes of the wave on ONE node"),
+                           ("inner_on_one_node_3_of_4_active", "inner steps with >= 3/4 of >= 16 active lanes on ONE node")):
+            v = ph.pop(key, (0, 0))[0]
+            print(f"   {label}: {v} lane-steps = {v / inner_lanes:.3f} of all inner lane-steps")
         for k, (e, l) in ph.items():
             if k == 'filter_violations': print('   filter_violations', e); continue
             if e: print(f"   {k:14s} wave-execs {e:12d}  lanes {l:13d}  util {l/(64*e):.3f}  execs/segment*64 {e*64/c['segments']:.2f}")
