@@ -1535,6 +1535,10 @@ static void fill_args(RtContext* ctx, int frame0, int nFrames, KArgs& a)
         a.raygenNoDefocus = (a.defocus == 0.0f && fin && noNegZero && std::isfinite(a.rcpW)) ? 1 : 0;
     }
     a.counters = ctx->dCounters;
+    a.travLimit = ctx->travLimit;
+    a.wavesPerGroup = 1; /* (choose_variant decides the workgroup shape of the trace kernels; the debug hooks run single waves without a cache) */
+    a.hotUnits = 0;
+    a.waveLdsDwords = 0;
 }
 
 } /* extern "C" */
@@ -1671,7 +1675,6 @@ static int choose_variant(RtContext* ctx, KArgs& a, LaunchPlan& plan, bool* many
     a.hotUnits = (int32_t)hotUnits;
     a.waveLdsDwords = (int32_t)(waveBytes / sizeof(uint32_t));
     a.stackEntries = ctx->stackEntries;
-    a.travLimit = ctx->travLimit;
     const bool many = ctx->nChunks > 0 && !ctx->flatScene;
     *manyOut = many;
     plan.kern = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_kernel<true, true> : rtk::rt_trace_kernel<false, true>)
