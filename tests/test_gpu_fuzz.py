@@ -256,8 +256,9 @@ def test_corrupted_but_accepted_scenes_bit_exact(pkg, api, orc, batch):
             assert np.array_equal(acc.view(np.uint32), want_acc.view(np.uint32)), what
             assert np.array_equal(frame.view(np.uint32), want_frame.view(np.uint32)), what
             assert c["segments"] == want_c["segments"], what
-            if k != 0:
-                for key in ("innerSteps", "leafSteps", "triTests", "modelVisits"):
-                    assert c[key] == want_c[key], (what, key, c[key], want_c[key])
+            # the STATS instantiation keeps every counter; the reference's text only its own two: stats[0] = triangle tests (RC:254) and
+            # stats[1] = box tests = 2 per inner node (RC:271)
+            for key in {0: (), 1: ("innerSteps", "leafSteps", "triTests", "modelVisits"), 3: ("innerSteps", "triTests")}[k]:
+                assert c[key] == want_c[key], (what, key, c[key], want_c[key])
         done += 1
     assert done == 40, (done, refused)
