@@ -1776,7 +1776,12 @@ static int prepare_staging(RtContext* ctx, KArgs& a, int nFrames, size_t nPix, i
             ctx->stagingBytes[b] = 0;
             /* room for the largest batch this context will ever form, so that a growing cap never re-makes a slab in the middle of a
              * render: as many frames as fit RT_FUSE_SLAB_BYTES, between RT_FUSE_MIN and RT_FUSE_MAX (the cap is held to what the slabs hold) */
-            size_t capFrames = nPix ? RT_FUSE_SLAB_BYTES / (nPix * 16) : RT_FUSE_MAX;
+            /* (sized ONCE, at the first fused launch, on purpose: growing a slab later costs a synchronise + an allocation of this size in the
+             * middle of a progressive render.  BVH scenes never batch more than RT_FUSE_MIN frames: a host that runs many contexts of such
+             * scenes lowers the budget with RT_FUSE_SLAB_MB — ADVICE r5) */
+            size_t slabBudget = RT_FUSE_SLAB_BYTES;
+            if (const char* e = getenv("RT_FUSE_SLAB_MB")) { const long long mb = atoll(e); if (mb > 0) slabBudget = (size_t)mb << 20; }
+            size_t capFrames = nPix ? slabBudget / (nPix * 16) : RT_FUSE_MAX;
             capFrames = capFrames < RT_FUSE_MIN ? RT_FUSE_MIN : capFrames > RT_FUSE_MAX ? RT_FUSE_MAX : capFrames;
             if (capFrames < (size_t)nFrames) capFrames = (size_t)nFrames;
             const size_t cap = capFrames * nPix * 16;
