@@ -23,8 +23,9 @@ cyclic 8-row strips (no data-path collective), scaling is STRONG by default (the
 each rank renders 1/N of its rows); the one RCCL gather of the accumulation tiles happens at readback,
 after the timed steps, and is reported as `gather_ms`.  `--scaling weak` grows the image with N instead.
 
-roofline (rank 0, N = 1): the headline kernel is VALU-issue bound, not memory bound (the BVH kernels of
---config 3..6 are bound by the vector-memory path, reported beside it as `roofline.memory_path`), so
+roofline (rank 0, N = 1): the trace kernels are bound by instruction issue at the occupancy their registers allow, not by memory
+(round 6 removed 39-47 % of the BVH kernels' L1 accesses with an LDS top-of-tree cache and their frame time moved by
+1-2 %: `roofline.memory_path` — L1 accesses per clock per CU, TA busy — is an observation, not a roof), so
 `bound` = "valu": achieved = SQ_INSTS_VALU per launch / average launch time, peak = 256 CU x 4 SIMD x
 2.4 GHz / 2 cycles per wave64 instruction, frac = achieved/peak x lane utilisation
 (SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)).  A "launch" is the dominant one of the timed region: the
@@ -64,9 +65,11 @@ HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 VALU_PEAK = 256 * 4 * 2.4e9 / 2.0          # wave64 VALU instructions / s: 256 CUs x 4 SIMD-32, 2 cycles each
 N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9
 N_CU = 256
-# The vector-memory path's roof (round 5; tools/ubench/vmem_gather.hip, profiles/r05_memory_path.txt): a CU's L1 (TCP) takes about ONE
+# The vector-memory path (round 5; tools/ubench/vmem_gather.hip, profiles/r05_memory_path.txt): a CU's L1 (TCP) takes about ONE
 # access per clock — a wave64 load is charged one access per group of neighbouring lanes that fall into one 128-byte line, 64 accesses in
-# 64.4 clocks when every lane has its own line — and no fewer than ~16 clocks per load instruction.  The BVH kernels sit at 0.83-0.92.
+# 64.4 clocks when every lane has its own line — and no fewer than ~16 clocks per load instruction.  Round 5 read the BVH kernels' 0.83-0.92
+# as their roof; round 6's LDS top-of-tree cache took them to 0.50-0.53 with 1-2 % less time (profiles/r06_what_binds_the_bvh_kernels.txt):
+# reported as an observation, `binding: False`.
 L1_ACCESS_PEAK = N_CU * CLOCK_HZ * 1.0
 KERNEL_LIKE = "%rt_trace%kernel<false%"    # the non-stats instantiations (whole-frame and half-frame names)
 
@@ -397,13 +400,13 @@ def launch_profile(pkg, api, dev_index, scene_id, W, H, launches, frames_per_lau
 
 
 def memory_path_roofline(pmc, launch_ms):
-    """The second roof of the trace kernels: L1 accesses per second against one access per clock per CU (see L1_ACCESS_PEAK).  For the
-    BVH workloads this, not VALU issue, is the binding one: 0.83-0.92 accesses per clock per CU, TA 71-85 % busy."""
+    """The vector-memory path of the trace kernels: L1 accesses per second against one access per clock per CU (see L1_ACCESS_PEAK).
+    NOT the binding roof (round 6: the LDS top-of-tree cache removed 39-47 % of these accesses, the frame time moved by 1-2 %)."""
     mp = pmc.get("memory_path")
     if not mp:
         return None
     achieved = mp["l1_accesses_per_launch"] / (launch_ms * 1e-3)
-    return {"bound": "l1_access", "achieved": achieved / 1e9, "peak": L1_ACCESS_PEAK / 1e9, "unit": "G L1 accesses/s", "frac": achieved / L1_ACCESS_PEAK,
+    return {"bound": "l1_access", "binding": False, "achieved": achieved / 1e9, "peak": L1_ACCESS_PEAK / 1e9, "unit": "G L1 accesses/s", "frac": achieved / L1_ACCESS_PEAK,
             "frac_at_measured_clock": mp["l1_accesses_per_clk_per_cu"], "ta_busy": mp["ta_busy"],
             "l1_accesses_per_vmem_read_inst": mp["l1_accesses_per_vmem_read_inst"], "l1_accesses_per_launch": mp["l1_accesses_per_launch"],
             "peak_derivation": "256 CUs x 2.4 GHz x 1 L1 (TCP) access per clock: tools/ubench/vmem_gather.hip measures 64 accesses of a wave64 global_load_dwordx4 "
@@ -621,6 +624,16 @@ def main():
     tracer.render_frames(args.steps)
     accumulated[0] += args.steps
     stats = tracer.counters()
+    lds_cache = None
+    try:   # BVH scenes: how many inner steps (lane-steps) the LDS top-of-tree cache served in the replayed K frames
+        ph = tracer.phase_profile()
+        if ph["inner"][1]:
+            lds_cache = {"inner_lane_steps": ph["inner"][1], "served_from_lds": ph["inner_from_lds_cache"][0],
+                         "fraction": ph["inner_from_lds_cache"][0] / ph["inner"][1],
+                         "steps_with_48_lanes_on_one_node": ph["inner_on_one_node_48_lanes"][0] / ph["inner"][1],
+                         "what": "the BVH kernels' workgroups (up to 12 waves) share an LDS copy of the top of the scene's trees; counted by the STATS instantiation over the timed frames"}
+    except Exception as e:  # informational
+        diagnostics.append(f"rank {rank}: phase profile: {type(e).__name__}: {e}")
     tracer.enable_stats(False)
     if stats["segments"] != segments:
         diagnostics.append(f"rank {rank}: stats replay counted {stats['segments']} segments, timed pass {segments}")
@@ -803,6 +816,7 @@ def main():
             "value_one_kernel_per_frame": (segments / args.steps / (single_ms * 1e-3) / 1e6) if single_ms else None,
             "value_fused_launches_one_stream": (launch_segments / (launch_ms * 1e-3) / 1e6) if launch_ms else None,
             "batched_api": batched,
+            "lds_top_of_tree_cache": lds_cache,
             "scene_load": scene_load,
             "parity": parity if parity is not None else "checked at N=1 (pytest -m gpu and the N=1 bench line)",
             "roofline": roof,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The last GPU action of a round: GPU test log, bench lines of every config + rocprofv3 profiles of the final build.
-# usage (GPU box): tools/final_round.sh <tag>      -> gpurun_out/<tag>/          (round 5: every step under its own timeout, ~20 min in all)
+# usage (GPU box): tools/final_round.sh <tag>      -> gpurun_out/<tag>/          (every step under its own timeout, ~20 min in all)
 TAG=${1:-final}; R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
 timeout -k 5 420 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $OUT/gpu_tests.txt
