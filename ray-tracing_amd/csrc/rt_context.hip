@@ -117,8 +117,8 @@ struct RtContext {
     long long nextSortAt = 1;
     bool lptEnabled = true;
     int numCUs = 256;
-    int occPerCU[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    size_t occBytes[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int occPerCU[16] = {0};
+    size_t occBytes[16] = {0};
     bool verbose = false;
     /* rt_render_frame calls that arrive while earlier frames are still executing are held back (at most
      * fuseCap) and leave as ONE fused launch at the next call that needs them (flush_pending) */
@@ -1184,6 +1184,11 @@ static int prepare_scene(RtContext* ctx, const RtModel* models, int n_models, co
             for (int i = 0; i < n_models; i++) anyInner = anyInner || !(rootCodes[i] & RT_CODE_LEAF);
             const GroupPlan gp = anyInner ? plan_groups(maxHeight, n_models) : GroupPlan();
             ps.wavesPerGroup = gp.wavesPerGroup;
+            /* Default rule (no `cache` word): the cache is used where it was measured to pay — scenes whose trees are small enough that the
+             * records the LDS holds are at least 1/16 of all node pairs (configs 3 and 6: 96 % / 73 % of the inner steps served, frame time
+             * 0 / - 1.1 % against the single-wave kernel; config 4 / 5 with 0.2 % / 0.01 % coverage: 63 % / 39 % served, + 3.6 % / - 0.3 %:
+             * profiles/r06_groups_and_streams.txt).  Without it the BVH variants are round 5's single-wave workgroups on two streams. */
+            if (L.cacheRecords == -1) L.cacheRecords = ((size_t)gp.cacheRecords * 16 >= nPairs) ? gp.cacheRecords : 0;
             if (L.cacheRecords < 0 || L.cacheRecords > gp.cacheRecords) L.cacheRecords = gp.cacheRecords;
             if (L.dense()) L.cacheRecords = 0; /* the dense layout moves nothing */
         }
@@ -1666,8 +1671,8 @@ static int choose_variant(RtContext* ctx, KArgs& a, LaunchPlan& plan, bool* many
     /* a wave: traversal stack + pixel fields + (more than 64 models) the mask extension: summary + words + the MANY variant's bounce row;
      * a workgroup of the BVH variants: the top-of-tree cache, then its waves' regions (plan_groups) */
     const size_t waveBytes = wave_lds_bytes(ctx->stackEntries, ctx->extWords) + coldBytes;
-    const int wpb = ctx->flatScene ? 1 : ctx->wavesPerGroup;
     const uint32_t hotUnits = ctx->flatScene ? 0u : ctx->hotUnits;
+    const int wpb = hotUnits ? ctx->wavesPerGroup : 1;
     plan.wavesPerGroup = wpb;
     plan.blockThreads = RT_WAVE * wpb;
     plan.ldsBytes = (size_t)hotUnits * 16 + (size_t)wpb * waveBytes;
@@ -1677,13 +1682,18 @@ static int choose_variant(RtContext* ctx, KArgs& a, LaunchPlan& plan, bool* many
     a.stackEntries = ctx->stackEntries;
     const bool many = ctx->nChunks > 0 && !ctx->flatScene;
     *manyOut = many;
+    const bool hot = hotUnits > 0; /* the instantiations with the LDS top-of-tree cache, launched as multi-wave workgroups */
     plan.kern = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_kernel<true, true> : rtk::rt_trace_kernel<false, true>)
-                : many         ? (ctx->stats ? rtk::rt_trace_kernel<true, false, true> : rtk::rt_trace_kernel<false, false, true>)
-                               : (ctx->stats ? rtk::rt_trace_kernel<true, false> : rtk::rt_trace_kernel<false, false>);
+                : many         ? (hot ? (ctx->stats ? rtk::rt_trace_kernel<true, false, true, true> : rtk::rt_trace_kernel<false, false, true, true>)
+                                      : (ctx->stats ? rtk::rt_trace_kernel<true, false, true> : rtk::rt_trace_kernel<false, false, true>))
+                               : (hot ? (ctx->stats ? rtk::rt_trace_kernel<true, false, false, true> : rtk::rt_trace_kernel<false, false, false, true>)
+                                      : (ctx->stats ? rtk::rt_trace_kernel<true, false> : rtk::rt_trace_kernel<false, false>));
     plan.kernHalf = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_half_kernel<true, true> : rtk::rt_trace_half_kernel<false, true>)
-                    : many         ? (ctx->stats ? rtk::rt_trace_half_kernel<true, false, true> : rtk::rt_trace_half_kernel<false, false, true>)
-                                   : (ctx->stats ? rtk::rt_trace_half_kernel<true, false> : rtk::rt_trace_half_kernel<false, false>);
-    plan.variant = (ctx->flatScene ? 2 : many ? 4 : 0) + (ctx->stats ? 1 : 0);
+                    : many         ? (hot ? (ctx->stats ? rtk::rt_trace_half_kernel<true, false, true, true> : rtk::rt_trace_half_kernel<false, false, true, true>)
+                                          : (ctx->stats ? rtk::rt_trace_half_kernel<true, false, true> : rtk::rt_trace_half_kernel<false, false, true>))
+                                   : (hot ? (ctx->stats ? rtk::rt_trace_half_kernel<true, false, false, true> : rtk::rt_trace_half_kernel<false, false, false, true>)
+                                          : (ctx->stats ? rtk::rt_trace_half_kernel<true, false> : rtk::rt_trace_half_kernel<false, false>));
+    plan.variant = (ctx->flatScene ? 2 : many ? 4 : 0) + (ctx->stats ? 1 : 0) + (hot ? 6 : 0);
     if (ctx->occBytes[plan.variant] != plan.ldsBytes + 1) { /* occupancy query cached per (variant, LDS bytes) */
         int perCU = 0;
         if (plan.ldsBytes > 48 * 1024) { /* more dynamic LDS than the default limit of a launch */
@@ -1998,7 +2008,13 @@ static int launch_frames(RtContext* ctx, int frame0, int nFrames)
      * accumulation buffer in FRAME order, are chained by events. */
     const bool staged = nFrames > 1;
     const size_t nPix = (size_t)ctx->localRows * ctx->W;
-    const bool twoOwn = ctx->twoStreams && ctx->stream == ctx->ownStream && ctx->sideStream;
+    /* Two kernels sharing the chip refill each other's freed wave slots one by one — with single-wave workgroups.  A 12-wave workgroup frees
+     * its slots and its LDS only when its LAST wave ends, and the other kernel's workgroups need twelve slots at once: overlapping launches then
+     * wait for each other instead of filling gaps (config 4 / 5: 7.8 / 50.2 ms per frame for K back-to-back rt_render_frame against 6.2 / 42.1 on
+     * one stream, profiles/r06_groups_and_streams.txt).  The BVH variants' group launches therefore stay on ONE stream, one kernel per launch;
+     * RT_GROUP_STREAMS=2 restores the overlap for A/B runs. */
+    static const bool groupsOverlap = getenv("RT_GROUP_STREAMS") && atoi(getenv("RT_GROUP_STREAMS")) == 2;
+    const bool twoOwn = ctx->twoStreams && ctx->stream == ctx->ownStream && ctx->sideStream && (plan.wavesPerGroup == 1 || groupsOverlap);
     const int lane = (staged && twoOwn && ctx->alternate) ? ctx->stagedNext : 0;
     if ((rc = prepare_tile_order(ctx, a, tiles, nFrames, lane, twoOwn))) return rc;
     if (staged) {

@@ -512,7 +512,7 @@ __device__ __forceinline__ void begin_intersect(const KArgs& a, rt_f3 rpos, rt_f
  * the stragglers keep their state in `t`/`h`/LDS and resume at the next call.  The loop has a
  * single, wave-uniform exit (finished lanes park in RT_CODE_DONE instead of leaving one by
  * one), which keeps the loop-carried state in one set of registers. */
-template <bool STATS, bool SUSPEND, bool MANY>
+template <bool STATS, bool SUSPEND, bool MANY, bool HOT = false>
 __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir, uint32_t* stackBase, uint32_t* extBase, SceneHit& h, Trav& t, Stats& st,
                                          const RT_LDS char* hotLds, const uint32_t hotUnits)
 {
@@ -618,7 +618,7 @@ __device__ __forceinline__ bool traverse(const KArgs& a, rt_f3 rpos, rt_f3 rdir,
                 const uint32_t cur = t.cur;
                 typedef float rt_v4f __attribute__((ext_vector_type(4))); /* (a plain vector type: HIP's float4 class cannot be read through an LDS-qualified pointer) */
                 rt_v4f q0, q1, q2, q3;
-                if (cur < hotUnits) {
+                if (HOT && cur < hotUnits) { /* HOT: the instantiation launched as multi-wave workgroups with the cache; without it the step is round 5's */
                     /* (LDS-typed pointers: with generic ones the optimiser merges the two branches into one select of addresses and
                      * nine flat loads — measured 35-88 % slower than no cache at all) */
                     const RT_LDS char* l = hotLds + (cur << 2);
@@ -804,18 +804,19 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
  * LDS: the per-lane traversal stack, [level][lane], sized by the host to the deepest
  * BVH of the scene (dynamic shared memory).
  * ------------------------------------------------------------------------- */
-template <bool STATS, bool FLAT, bool MANY>
+template <bool STATS, bool FLAT, bool MANY, bool HOT>
 __device__ __forceinline__ void trace_body(const KArgs& a)
 {
     /* A workgroup is wavesPerGroup waves (1 for the FLAT variant) that share ONE thing: the LDS copy of the top of the scene's trees
      * (traverse(), phase B).  LDS: [hot cache: hotUnits x 16 B][wave 0: stack, pixel fields, ...][wave 1: ...] ...  After the fill and its
      * one barrier the waves never meet again: each is the persistent wave of rounds 1-5 with the global wave index gw where blockIdx.x was. */
     extern __shared__ uint32_t s_lds[];
-    const int lane = threadIdx.x & (RT_WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t hotUnits = FLAT ? 0u : (uint32_t)a.hotUnits;
+    static_assert(!(HOT && FLAT), "the FLAT variant has no tree");
+    const int lane = HOT ? (int)(threadIdx.x & (RT_WAVE - 1)) : (int)threadIdx.x;
+    const int wave = HOT ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const uint32_t hotUnits = HOT ? (uint32_t)a.hotUnits : 0u;
     const RT_LDS char* const hotLds = (const RT_LDS char*)s_lds;
-    if (!FLAT && hotUnits) {
+    if (HOT && hotUnits) {
         /* unit i = quarter (i & 3) of record (i >> 2): coalesced 16-byte loads of the pair space's first hotUnits units */
         const float4* src = reinterpret_cast<const float4*>(a.pairs);
         float4* dst = reinterpret_cast<float4*>(s_lds);
@@ -823,8 +824,8 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
         for (uint32_t i = threadIdx.x; i < hotUnits; i += blockDim.x) dst[(i & 3u) * nHot + (i >> 2)] = src[i];
         __syncthreads();
     }
-    uint32_t* const s_stack = s_lds + (FLAT ? 0u : hotUnits * 4u + (uint32_t)wave * (uint32_t)a.waveLdsDwords);
-    const int gw = FLAT ? (int)blockIdx.x : (int)blockIdx.x * a.wavesPerGroup + wave; /* this wave among the launch's waves */
+    uint32_t* const s_stack = HOT ? s_lds + (hotUnits * 4u + (uint32_t)wave * (uint32_t)a.waveLdsDwords) : s_lds;
+    const int gw = HOT ? (int)blockIdx.x * a.wavesPerGroup + wave : (int)blockIdx.x; /* this wave among the launch's waves */
     uint32_t* stackBase = &s_stack[lane];
 
     /* Persistent wave: the wave starts on tile blockIdx.x and, whenever lanes run out of
@@ -1072,7 +1073,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                 if (FLAT) traverse_flat<STATS>(a, rpos, rdir, h, st);
             }
         }
-        if (inTrav && (FLAT || traverse<STATS, true, MANY>(a, rpos, rdir, stackBase, extBase, h, t, st, hotLds, hotUnits))) {
+        if (inTrav && (FLAT || traverse<STATS, true, MANY, HOT>(a, rpos, rdir, stackBase, extBase, h, t, st, hotLds, hotUnits))) {
             inTrav = false;
             /* the rest of one iteration of Trace's bounce loop — RC:488-538 */
             bool endPath = false;
@@ -1202,15 +1203,15 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
  * overlap in time), separately. */
 /* MANY: scenes with more than 64 models (two-level filter, candidate masks extended into LDS) — a separate
  * instantiation so that the common case keeps its registers */
-template <bool STATS, bool FLAT, bool MANY = false>
-__global__ void __launch_bounds__(FLAT ? RT_WAVE : RT_WAVE * RT_MAX_WAVES_PER_GROUP, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : MANY ? RT_MIN_WAVES_PER_SIMD_MANY : RT_MIN_WAVES_PER_SIMD) rt_trace_kernel(const KArgs a)
+template <bool STATS, bool FLAT, bool MANY = false, bool HOT = false>
+__global__ void __launch_bounds__(HOT ? RT_WAVE * RT_MAX_WAVES_PER_GROUP : RT_WAVE, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : MANY ? RT_MIN_WAVES_PER_SIMD_MANY : RT_MIN_WAVES_PER_SIMD) rt_trace_kernel(const KArgs a)
 {
-    trace_body<STATS, FLAT, MANY>(a);
+    trace_body<STATS, FLAT, MANY, HOT>(a);
 }
-template <bool STATS, bool FLAT, bool MANY = false>
-__global__ void __launch_bounds__(FLAT ? RT_WAVE : RT_WAVE * RT_MAX_WAVES_PER_GROUP, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : MANY ? RT_MIN_WAVES_PER_SIMD_MANY : RT_MIN_WAVES_PER_SIMD) rt_trace_half_kernel(const KArgs a)
+template <bool STATS, bool FLAT, bool MANY = false, bool HOT = false>
+__global__ void __launch_bounds__(HOT ? RT_WAVE * RT_MAX_WAVES_PER_GROUP : RT_WAVE, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : MANY ? RT_MIN_WAVES_PER_SIMD_MANY : RT_MIN_WAVES_PER_SIMD) rt_trace_half_kernel(const KArgs a)
 {
-    trace_body<STATS, FLAT, MANY>(a);
+    trace_body<STATS, FLAT, MANY, HOT>(a);
 }
 
 /* ---- test hooks (rt_debug_*): the same device functions, one ray / value per lane */

@@ -21,7 +21,8 @@
  *               down by the world-space surface area of the node they belong to, summed over the models that share the tree —
  *               lie at units [0, 4N) of the pair space, in front of every instance; the BVH kernels' workgroups copy exactly that
  *               prefix into LDS (rt_kernels.h, traverse phase B).  cache (no number) / default = as many as the LDS of a
- *               workgroup has room for (rt_context.hip, plan_groups); cache=0 = none
+ *               workgroup has room for (rt_context.hip, plan_groups); cache=0 = none; no word at all = the default rule: as many as fit
+ *               when they cover at least 1/16 of the scene's node pairs, else none (prepare_scene: where the cache was measured to pay)
  * Anything but `dense` needs a regular scene (no node pair shared between meshes, referenced triangles not much more
  * than the triangles there are); an irregular one silently gets `dense`.
  */
@@ -96,7 +97,8 @@ struct RtLayout {
     bool preorder = false;
     int triMode = 0; /* 0 dense, 1 align, 2 arena */
     bool pairAlign = false;
-    int cacheRecords = -1; /* node pairs in the hot prefix of the pair space: -1 = what the workgroups' LDS holds, 0 = none */
+    int cacheRecords = -1; /* node pairs in the hot prefix of the pair space: -1 = default rule (what the workgroups' LDS holds IF that covers
+                            * enough of the scene's pairs to pay, rt_context.hip prepare_scene), -2 = what the LDS holds, 0 = none */
     bool dense() const { return hotLevels == 0 && !preorder && triMode == 0; }
     std::string name() const
     {
@@ -141,7 +143,7 @@ static inline bool parse_layout(const char* s, RtLayout* out)
         if (w == "" || w == "dense" || w == "post") { }
         else if (w == "pre") L.preorder = true;
         else if (w.compare(0, 4, "hot=") == 0) { if (!parse_count(w.c_str() + 4, 24, &L.hotLevels)) return false; }
-        else if (w == "cache") L.cacheRecords = -1;
+        else if (w == "cache") L.cacheRecords = -2; /* as many as fit, whatever the scene's size (-1, the default, applies the coverage rule) */
         else if (w.compare(0, 6, "cache=") == 0) { if (!parse_count(w.c_str() + 6, 1 << 16, &L.cacheRecords)) return false; }
         else if (w == "align") L.triMode = 1;
         else if (w == "arena") L.triMode = 2;
