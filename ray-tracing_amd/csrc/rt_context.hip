@@ -89,6 +89,7 @@ struct RtContext {
     int stackEntries = 1; /* deepest BVH of the scene = most entries a lane can push */
     int wavesPerGroup = 1; /* the BVH variants' workgroups: waves that share one LDS top-of-tree cache (plan_groups) */
     uint32_t hotUnits = 0; /* units [0, hotUnits) of the pair space are that cache's records */
+    int poolWaves = 1, poolCells = 0; /* the FLAT variant's workgroups: waves that share one LDS chain pool of 2 x poolCells cells (rt_kernels.h, pool_exchange); 0 cells = no pool */
     uint32_t travLimit = 1u << 20; /* traversal watchdog (rt_kernels.h, traverse): 64 x the steps one ray can take in this scene */
     bool haveScene = false;
     /* scene (host mirrors needed by rt_update_models) */
@@ -1285,6 +1286,21 @@ static int commit_scene(RtContext* ctx, const PreparedScene& ps, const RtContext
         if (const char* e = getenv("RT_TRAV_LIMIT")) ctx->travLimit = (uint32_t)strtoul(e, nullptr, 10); /* test hook: make the watchdog fire */
     }
     ctx->wavesPerGroup = ctx->hotUnits ? ps.wavesPerGroup : 1;
+    {   /* the FLAT variant's chain pool (rt_kernels.h, pool_exchange): 16-wave workgroups (two per CU at the variant's 8 waves per SIMD), two
+         * queues of 64 cells of 128 bytes — 17 KB of the workgroup's 70 KB.  RT_POOL=0: single-wave workgroups without a pool (rounds 1-5);
+         * RT_POOL_WAVES / RT_POOL_CELLS (a power of two): A/B runs and tests */
+        int on = 1, waves = RT_MAX_WAVES_PER_GROUP_FLAT, cells = 64;
+        if (const char* e = getenv("RT_POOL")) on = atoi(e);
+        if (const char* e = getenv("RT_POOL_WAVES")) waves = atoi(e);
+        if (const char* e = getenv("RT_POOL_CELLS")) cells = atoi(e);
+        if (waves < 1) waves = 1;
+        if (waves > RT_MAX_WAVES_PER_GROUP_FLAT) waves = RT_MAX_WAVES_PER_GROUP_FLAT;
+        while (cells & (cells - 1)) cells &= cells - 1; /* round down to a power of two */
+        if (cells > 1024) cells = 1024;
+        const bool pooled = ps.flat && on && cells >= 2;
+        ctx->poolWaves = pooled ? waves : 1;
+        ctx->poolCells = pooled ? cells : 0;
+    }
     ctx->hModels = ps.hModels;
     ctx->hRootCodes = ps.rootCodes;
     ctx->haveScene = true;
@@ -1544,6 +1560,7 @@ static void fill_args(RtContext* ctx, int frame0, int nFrames, KArgs& a)
     a.wavesPerGroup = 1; /* (choose_variant decides the workgroup shape of the trace kernels; the debug hooks run single waves without a cache) */
     a.hotUnits = 0;
     a.waveLdsDwords = 0;
+    a.poolCells = 0;
 }
 
 } /* extern "C" */
@@ -1671,24 +1688,29 @@ static int choose_variant(RtContext* ctx, KArgs& a, LaunchPlan& plan, bool* many
     /* a wave: traversal stack + pixel fields + (more than 64 models) the mask extension: summary + words + the MANY variant's bounce row;
      * a workgroup of the BVH variants: the top-of-tree cache, then its waves' regions (plan_groups) */
     const size_t waveBytes = wave_lds_bytes(ctx->stackEntries, ctx->extWords) + coldBytes;
-    const uint32_t hotUnits = ctx->flatScene ? 0u : ctx->hotUnits;
-    const int wpb = hotUnits ? ctx->wavesPerGroup : 1;
+    /* the shared region in front of the waves' regions: the BVH variants' top-of-tree cache, or the FLAT variant's chain pool */
+    const bool pooled = ctx->flatScene && ctx->poolCells > 0;
+    const uint32_t hotUnits = ctx->flatScene ? (pooled ? (uint32_t)(RT_POOL_DWORDS(ctx->poolCells) / 4) : 0u) : ctx->hotUnits;
+    const int wpb = ctx->flatScene ? (pooled ? ctx->poolWaves : 1) : (hotUnits ? ctx->wavesPerGroup : 1);
     plan.wavesPerGroup = wpb;
     plan.blockThreads = RT_WAVE * wpb;
     plan.ldsBytes = (size_t)hotUnits * 16 + (size_t)wpb * waveBytes;
     a.wavesPerGroup = wpb;
     a.hotUnits = (int32_t)hotUnits;
+    a.poolCells = pooled ? ctx->poolCells : 0;
     a.waveLdsDwords = (int32_t)(waveBytes / sizeof(uint32_t));
     a.stackEntries = ctx->stackEntries;
     const bool many = ctx->nChunks > 0 && !ctx->flatScene;
     *manyOut = many;
-    const bool hot = hotUnits > 0; /* the instantiations with the LDS top-of-tree cache, launched as multi-wave workgroups */
-    plan.kern = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_kernel<true, true> : rtk::rt_trace_kernel<false, true>)
+    const bool hot = hotUnits > 0; /* the instantiations launched as multi-wave workgroups: with the LDS top-of-tree cache, or (FLAT) the chain pool */
+    plan.kern = ctx->flatScene ? (pooled ? (ctx->stats ? rtk::rt_trace_kernel<true, true, false, true> : rtk::rt_trace_kernel<false, true, false, true>)
+                                         : (ctx->stats ? rtk::rt_trace_kernel<true, true> : rtk::rt_trace_kernel<false, true>))
                 : many         ? (hot ? (ctx->stats ? rtk::rt_trace_kernel<true, false, true, true> : rtk::rt_trace_kernel<false, false, true, true>)
                                       : (ctx->stats ? rtk::rt_trace_kernel<true, false, true> : rtk::rt_trace_kernel<false, false, true>))
                                : (hot ? (ctx->stats ? rtk::rt_trace_kernel<true, false, false, true> : rtk::rt_trace_kernel<false, false, false, true>)
                                       : (ctx->stats ? rtk::rt_trace_kernel<true, false> : rtk::rt_trace_kernel<false, false>));
-    plan.kernHalf = ctx->flatScene ? (ctx->stats ? rtk::rt_trace_half_kernel<true, true> : rtk::rt_trace_half_kernel<false, true>)
+    plan.kernHalf = ctx->flatScene ? (pooled ? (ctx->stats ? rtk::rt_trace_half_kernel<true, true, false, true> : rtk::rt_trace_half_kernel<false, true, false, true>)
+                                             : (ctx->stats ? rtk::rt_trace_half_kernel<true, true> : rtk::rt_trace_half_kernel<false, true>))
                     : many         ? (hot ? (ctx->stats ? rtk::rt_trace_half_kernel<true, false, true, true> : rtk::rt_trace_half_kernel<false, false, true, true>)
                                           : (ctx->stats ? rtk::rt_trace_half_kernel<true, false, true> : rtk::rt_trace_half_kernel<false, false, true>))
                                    : (hot ? (ctx->stats ? rtk::rt_trace_half_kernel<true, false, false, true> : rtk::rt_trace_half_kernel<false, false, false, true>)

@@ -790,6 +790,157 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 }
 
 /* ---------------------------------------------------------------------------
+ * The FLAT variant's CHAIN POOL (round 6): active-ray compaction across the waves of a workgroup.
+ *
+ * After the intersection every lane's chain wants ONE of two exclusive phases — `sky` (a miss, RC:488-492: two pow, ends the path)
+ * or `shade` (a hit, RC:494-538) — and a wave that runs both for half of its lanes each is where the headline kernel loses its lanes
+ * (lane utilisation 0.50 / 0.63 in the two phases, 57 % of the instructions of an iteration).  A pixel's samples and bounces are one
+ * serial RNG chain (quirk Q13), but WHICH lane of WHICH wave runs the next link is free: the chain is 32 dwords of state.  The waves of
+ * a workgroup therefore share two bounded queues in LDS — chains waiting for `sky`, chains waiting for `shade` — and at this point
+ * of every iteration a wave
+ *   - picks as its target the phase with the larger demand (its own lanes + the queue's chains),
+ *   - DEPOSITS the chains of its other lanes (as far as that queue has room), and
+ *   - WITHDRAWS chains of the target phase into every lane that is empty now (just deposited, or out of pixels),
+ * then runs the phases as before — for (nearly) all 64 lanes the target phase, the other one only for lanes the full queue kept.
+ * An emptied lane takes the next pixel at the top of the loop like any idle lane, so a workgroup carries up to 2 x poolCells more chains
+ * than it has lanes.  Same arithmetic per chain, same order of a pixel's samples, frames staged and added in frame order as before:
+ * same bits (tools/sched_sim_pool.py is the model that said -12 ... -16 % instructions before this was written).
+ *
+ * Queues: bounded multi-producer / multi-consumer rings with a sequence word per cell.  A wave reserves n cells with ONE compare-and-swap
+ * on the queue's tail (deposit) or head (withdraw) by its first lane; lane r then owns position p = base + r, cell p mod C:
+ *   deposit : wait until seq[cell] == p (the reader of the previous lap is done), write the payload, seq[cell] = p + 1 (release)
+ *   withdraw: wait until seq[cell] == p + 1 (the writer is done), read the payload, seq[cell] = p + C (release: free for the next lap)
+ * Every wait is for a wave that is in the middle of straight-line code of the same kind on an EARLIER position, so waits cannot form a
+ * cycle; a wave never exits while it holds a chain or a queue is non-empty (trace_body), so every deposited chain is withdrawn by a
+ * live wave.  A wait that exceeds RT_POOL_SPIN_LIMIT polls raises the watchdog counter (slot 7: rt_get_counters / rt_read_* then FAIL)
+ * and goes on — a broken pool must cost a wrong image that says so, never a hung device.
+ * ------------------------------------------------------------------------- */
+#ifndef RT_POOL_SPIN_LIMIT
+#define RT_POOL_SPIN_LIMIT (1u << 16)
+#endif
+#define RT_POOL_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define RT_POOL_LOAD_ACQ(p) __hip_atomic_load((p), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define RT_POOL_STORE_REL(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define RT_RFL(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))
+template <bool STATS>
+__device__ __forceinline__ void pool_exchange(const KArgs& a, uint32_t* const pool, const uint32_t C, const int lane, uint32_t* const pxu, float4* const cold,
+                                              bool& laneDone, bool& pathActive, bool& inTrav, rt_f3& rpos, rt_f3& rdir, rt_f3& transmittance, rt_f3& pathLight,
+                                              uint32_t& rng, int& bounce, SceneHit& h, const uint32_t segments, Stats& st)
+{
+    const bool wantSky = !laneDone && inTrav && h.obj < 0;
+    const bool wantShade = !laneDone && inTrav && h.obj >= 0;
+    const unsigned long long mS = __ballot(wantSky), mH = __ballot(wantShade);
+    unsigned long long mE = __ballot(laneDone);
+    const int nS = __popcll(mS), nH = __popcll(mH);
+    /* queue 0 = sky, queue 1 = shade; header dwords: head0 tail0 head1 tail1 (every lane reads the same address: an LDS broadcast) */
+    const int qS = (int)(RT_RFL(RT_POOL_LOAD(pool + 1)) - RT_RFL(RT_POOL_LOAD(pool + 0)));
+    const int qH = (int)(RT_RFL(RT_POOL_LOAD(pool + 3)) - RT_RFL(RT_POOL_LOAD(pool + 2)));
+    const bool tgtShade = nH + qH >= nS + qS;
+    const unsigned long long mOther = tgtShade ? mS : mH;
+    const int nOther = __popcll(mOther);
+    if (nOther == 0 && (mE == 0ull || (tgtShade ? qH : qS) <= 0)) return; /* nothing to hand over, nobody to take anything */
+    const uint32_t qo = tgtShade ? 0u : 1u, qt = 1u - qo;
+    uint32_t* const seq = pool + RT_POOL_HEADER_DWORDS;
+    float4* const payload = reinterpret_cast<float4*>(pool + RT_POOL_HEADER_DWORDS + 2u * C);
+    bool broken = false;
+    /* ---- deposit the lanes of the other phase */
+    if (nOther) {
+        uint32_t* const headp = pool + 2u * qo;
+        uint32_t* const tailp = headp + 1;
+        uint32_t base = 0u;
+        int nDep = 0;
+        for (int tries = 0; tries < 64; tries++) { /* wave-uniform; a failed compare-and-swap means another wave moved the tail: look again */
+            const uint32_t hh = RT_RFL(RT_POOL_LOAD(headp)), tt = RT_RFL(RT_POOL_LOAD(tailp)); /* head first: the room is never overestimated */
+            const int room = (int)C - (int)(tt - hh);
+            const int n = nOther < room ? nOther : room;
+            if (n <= 0) break;
+            uint32_t old = tt;
+            if (lane == 0) old = atomicCAS(tailp, tt, tt + (uint32_t)n);
+            old = RT_RFL(old);
+            if (old == tt) { base = tt; nDep = n; break; }
+        }
+        if (nDep) {
+            const int rank = __popcll(mOther & ((1ull << lane) - 1ull));
+            if ((tgtShade ? wantSky : wantShade) && rank < nDep) {
+                const uint32_t pos = base + (uint32_t)rank, cell = pos & (C - 1u);
+                uint32_t* const sp = seq + qo * C + cell;
+                uint32_t spins = 0u;
+                while (RT_POOL_LOAD_ACQ(sp) != pos) {
+                    if (++spins > RT_POOL_SPIN_LIMIT) { broken = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                float4* const q = payload + (size_t)(qo * RT_POOL_QUADS) * C + cell; /* quad j of the cell: q[j * C] */
+                const float4 rec1 = cold[RT_WAVE];
+                q[0 * C] = make_float4(rpos.x, rpos.y, rpos.z, __uint_as_float(rng));
+                q[1 * C] = make_float4(rdir.x, rdir.y, rdir.z, __uint_as_float((uint32_t)bounce));
+                q[2 * C] = make_float4(transmittance.x, transmittance.y, transmittance.z, h.dst);
+                q[3 * C] = make_float4(pathLight.x, pathLight.y, pathLight.z, __uint_as_float((uint32_t)h.obj));
+                q[4 * C] = make_float4(__uint_as_float((uint32_t)h.tri), h.u, h.v, h.det);
+                q[5 * C] = make_float4(__uint_as_float(pxu[0 * RT_WAVE]), __uint_as_float(pxu[1 * RT_WAVE]), __uint_as_float(pxu[2 * RT_WAVE]), __uint_as_float(pxu[3 * RT_WAVE]));
+                q[6 * C] = cold[0];
+                /* the record's second word = `segments` of the LANE when the pixel was set up (tile cost = the chain's segments so far): it travels as the
+                 * chain's own count and is re-based on the taker's counter; the spare fourth word carries the hit's backface flag */
+                q[7 * C] = make_float4(rec1.x, __uint_as_float(segments - __float_as_uint(rec1.y)), rec1.z, __uint_as_float(h.backface ? 1u : 0u));
+                RT_POOL_STORE_REL(sp, pos + 1u);
+                laneDone = true;
+                inTrav = false;
+                pathActive = false;
+                if (STATS) st.hotSteps++;
+            }
+            mE = __ballot(laneDone);
+        }
+    }
+    /* ---- withdraw chains of the target phase into the empty lanes */
+    if (mE) {
+        const int nWant = __popcll(mE);
+        uint32_t* const headp = pool + 2u * qt;
+        uint32_t* const tailp = headp + 1;
+        uint32_t base = 0u;
+        int nW = 0;
+        for (int tries = 0; tries < 64; tries++) {
+            const uint32_t hh = RT_RFL(RT_POOL_LOAD(headp)), tt = RT_RFL(RT_POOL_LOAD(tailp));
+            const int avail = (int)(tt - hh); /* reserved by their writers, possibly still being written: the sequence word says when */
+            const int n = nWant < avail ? nWant : avail;
+            if (n <= 0) break;
+            uint32_t old = hh;
+            if (lane == 0) old = atomicCAS(headp, hh, hh + (uint32_t)n);
+            old = RT_RFL(old);
+            if (old == hh) { base = hh; nW = n; break; }
+        }
+        if (nW) {
+            const int rank = __popcll(mE & ((1ull << lane) - 1ull));
+            if (laneDone && rank < nW) {
+                const uint32_t pos = base + (uint32_t)rank, cell = pos & (C - 1u);
+                uint32_t* const sp = seq + qt * C + cell;
+                uint32_t spins = 0u;
+                while (RT_POOL_LOAD_ACQ(sp) != pos + 1u) {
+                    if (++spins > RT_POOL_SPIN_LIMIT) { broken = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const float4* const q = payload + (size_t)(qt * RT_POOL_QUADS) * C + cell;
+                const float4 q0 = q[0 * C], q1 = q[1 * C], q2 = q[2 * C], q3 = q[3 * C], q4 = q[4 * C], q5 = q[5 * C], q6 = q[6 * C], q7 = q[7 * C];
+                RT_POOL_STORE_REL(sp, pos + C);
+                rpos = rt_v3(q0.x, q0.y, q0.z); rng = __float_as_uint(q0.w);
+                rdir = rt_v3(q1.x, q1.y, q1.z); bounce = (int)__float_as_uint(q1.w);
+                transmittance = rt_v3(q2.x, q2.y, q2.z); h.dst = q2.w;
+                pathLight = rt_v3(q3.x, q3.y, q3.z); h.obj = (int)__float_as_uint(q3.w);
+                h.tri = (int)__float_as_uint(q4.x); h.u = q4.y; h.v = q4.z; h.det = q4.w;
+                pxu[0 * RT_WAVE] = __float_as_uint(q5.x); pxu[1 * RT_WAVE] = __float_as_uint(q5.y); pxu[2 * RT_WAVE] = __float_as_uint(q5.z); pxu[3 * RT_WAVE] = __float_as_uint(q5.w);
+                cold[0] = q6;
+                cold[RT_WAVE] = make_float4(q7.x, __uint_as_float(segments - __float_as_uint(q7.y)), q7.z, 0.0f);
+                h.backface = __float_as_uint(q7.w) != 0u;
+                laneDone = false;
+                inTrav = true;
+                pathActive = true;
+            }
+        }
+    }
+    if (__ballot(broken)) { /* wave-uniform */
+        if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) atomicAdd(a.counters + 7, 1ull); /* (the lane index recomputed: this path must not keep a register alive) */
+    }
+}
+
+/* ---------------------------------------------------------------------------
  * The trace kernel: RayTrace (RCC:10-24) -> RayTrace(uv) (RC:545-582) -> Trace (RC:479-542).
  *
  * One wave64 per 8x8 tile, one lane per pixel.  A lane is a small state machine over
@@ -811,12 +962,19 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
      * (traverse(), phase B).  LDS: [hot cache: hotUnits x 16 B][wave 0: stack, pixel fields, ...][wave 1: ...] ...  After the fill and its
      * one barrier the waves never meet again: each is the persistent wave of rounds 1-5 with the global wave index gw where blockIdx.x was. */
     extern __shared__ uint32_t s_lds[];
-    static_assert(!(HOT && FLAT), "the FLAT variant has no tree");
+    /* FLAT && HOT: the FLAT variant launched as multi-wave workgroups that share the CHAIN POOL (pool_exchange) in place of a tree cache */
+    constexpr bool POOL = FLAT && HOT;
     const int lane = HOT ? (int)(threadIdx.x & (RT_WAVE - 1)) : (int)threadIdx.x;
     const int wave = HOT ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     const uint32_t hotUnits = HOT ? (uint32_t)a.hotUnits : 0u;
     const RT_LDS char* const hotLds = (const RT_LDS char*)s_lds;
-    if (HOT && hotUnits) {
+    if (POOL) {
+        /* both queues empty: head = tail = 0, cell c free for position c (pool_exchange) */
+        const uint32_t C = (uint32_t)a.poolCells;
+        for (uint32_t i = threadIdx.x; i < RT_POOL_HEADER_DWORDS + 2u * C; i += blockDim.x) s_lds[i] = i < RT_POOL_HEADER_DWORDS ? 0u : ((i - RT_POOL_HEADER_DWORDS) & (C - 1u));
+        __syncthreads();
+    }
+    if (HOT && !FLAT && hotUnits) {
         /* unit i = quarter (i & 3) of record (i >> 2): coalesced 16-byte loads of the pair space's first hotUnits units */
         const float4* src = reinterpret_cast<const float4*>(a.pairs);
         float4* dst = reinterpret_cast<float4*>(s_lds);
@@ -970,7 +1128,97 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
             poolPos += wanted < avail ? wanted : avail;
             idle = __ballot(laneDone);
         }
-        if (idle == ~0ull) break; /* nothing left anywhere */
+        if (idle == ~0ull) { /* no lane holds a chain and the queue has no pixel left */
+            if (!POOL) break;
+            /* ... a wave of a pooled workgroup stays while a queue of the pool holds (or is being handed) a chain: whoever is alive takes it */
+            if (RT_RFL(RT_POOL_LOAD(s_lds + 0)) == RT_RFL(RT_POOL_LOAD(s_lds + 1)) && RT_RFL(RT_POOL_LOAD(s_lds + 2)) == RT_RFL(RT_POOL_LOAD(s_lds + 3))) break;
+        }
+        /* the second half of an iteration — the rest of one iteration of Trace's bounce loop for the lanes whose intersection is complete —
+         * as a callable: the pooled FLAT variant runs the chain exchange between the halves with every lane of the wave present */
+        auto shade_phase = [&]() __attribute__((always_inline)) {
+        if (inTrav && (FLAT || traverse<STATS, true, MANY, HOT>(a, rpos, rdir, stackBase, extBase, h, t, st, hotLds, hotUnits))) {
+            inTrav = false;
+            /* the rest of one iteration of Trace's bounce loop — RC:488-538 */
+            bool endPath = false;
+            if (h.obj < 0) {
+                phase_mark<STATS>(st, PH_SKY);
+                const RT_CAS KArgs& c = cold_args();
+                if (c.useSky) pathLight = pathLight + transmittance * environment_light(c, rdir);
+                endPath = true;
+            } else {
+                /* resolve the winner: position, normal, material */
+                phase_mark<STATS>(st, PH_SHADE_HIT);
+                rt_f3 hpos, normal;
+                resolve_hit(a, rpos, rdir, h, hpos, normal);
+                const DMaterial mat = a.materials[h.obj];
+
+                /* The glass (RC:499-518) and opaque (RC:519-533) branches both draw
+                 * diffuseDir = normalize(normal + RandomDirection) — the costliest piece
+                 * (3 log, 3 cos, 4 sqrt).  It is hoisted so that all hit lanes execute it
+                 * together; each lane still consumes its random numbers in its branch's
+                 * order: opaque = [isSpecular, direction x6], glass = [direction x6, choice]. */
+                const bool isGlass = mat.flag == RT_MATERIAL_GLASS;
+                float uSpec = 0.0f;
+                if (!isGlass) uSpec = rt_random_value(&rng); /* RC:521 */
+                const rt_f3 diffuseDir = rt_normalize(normal + rand_direction(&rng)); /* RC:509 / RC:525 */
+                /* Both branches end in normalize(lerp(A, B, t)) of a direction pair: opaque (diffuseDir, reflect, smoothness x
+                 * isSpecular), glass either (diffuseDir, reflect, specularProbability) or (-diffuseDir, refract, smoothness).  The
+                 * reference normalises both glass candidates and keeps one (RC:511-516); only the kept one is observable, so the
+                 * branches just pick (A, B, t) and ONE lerp + normalize follows for all hit lanes. */
+                const rt_f3 specularDir = rt_reflect(rdir, normal); /* == the glass branch's reflectDir, RC:419-422 */
+                rt_f3 lerpA = diffuseDir, lerpB = specularDir;
+                float lerpT;
+                if (isGlass) {
+                    phase_mark<STATS>(st, PH_GLASS);
+                    if (h.backface) { /* RC:502 */
+                        rt_f3 e = ((-h.dst) * rt_v3(mat.absorption[0], mat.absorption[1], mat.absorption[2])) * mat.absorptionStrength;
+                        transmittance = transmittance * rt_v3(rt_exp(e.x), rt_exp(e.y), rt_exp(e.z));
+                    }
+                    float iorCurrent = h.backface ? mat.ior : 1.0f;
+                    float iorNext = h.backface ? 1.0f : mat.ior;
+                    const rt_f3 refractDir = refract_dir(rdir, normal, iorCurrent, iorNext);
+                    const float reflectWeight = reflectance(rdir, normal, iorCurrent, iorNext);
+                    const bool followReflection = rt_random_value(&rng) <= reflectWeight; /* RC:515 */
+                    lerpT = mat.specularProbability;
+                    if (!followReflection) {
+                        lerpA = -diffuseDir;
+                        lerpB = refractDir;
+                        lerpT = mat.smoothness;
+                    }
+                } else {
+                    const bool isSpecular = mat.specularProbability >= uSpec;
+                    lerpT = mat.smoothness * (isSpecular ? 1.0f : 0.0f);
+                    rt_f3 emitted = rt_v3(mat.emissionCol[0], mat.emissionCol[1], mat.emissionCol[2]) * mat.emissionStrength;
+                    pathLight = pathLight + emitted * transmittance;
+                    transmittance = transmittance * material_colour(mat, hpos, normal, isSpecular);
+                }
+                rdir = rt_normalize(rt_lerp3(lerpA, lerpB, lerpT));
+                rpos = isGlass ? hpos + (0.001f * normal) * rt_sign(rt_dot(normal, rdir)) : hpos + (normal * 0.001f);
+                /* RC:535-538 Russian roulette */
+                float p = rt_max(transmittance.x, rt_max(transmittance.y, transmittance.z));
+                if (rt_random_value(&rng) >= p) {
+                    endPath = true;
+                } else {
+                    transmittance = transmittance * rt_rcp(p);
+                    if (MANY) {
+                        const uint32_t b = extBase[(1 + a.extWords) * RT_WAVE] + 1u;
+                        extBase[(1 + a.extWords) * RT_WAVE] = b;
+                        if ((int)b > a.maxBounce) endPath = true;
+                    } else {
+                        bounce++;
+                        if (bounce > a.maxBounce) endPath = true; /* RC:485: i <= MaxBounceCount */
+                    }
+                }
+            }
+            if (endPath) {
+                PXF(PX_TIX) = PXF(PX_TIX) + pathLight.x; /* RC:578: totalIncomingLight += Trace(...) */
+                PXF(PX_TIY) = PXF(PX_TIY) + pathLight.y;
+                PXF(PX_TIZ) = PXF(PX_TIZ) + pathLight.z;
+                pathActive = false;
+            }
+        
+        }
+        };
         if (!laneDone) {
         phase_mark<STATS>(st, PH_LOOP);
         if (!inTrav) {
@@ -1073,88 +1321,12 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                 if (FLAT) traverse_flat<STATS>(a, rpos, rdir, h, st);
             }
         }
-        if (inTrav && (FLAT || traverse<STATS, true, MANY, HOT>(a, rpos, rdir, stackBase, extBase, h, t, st, hotLds, hotUnits))) {
-            inTrav = false;
-            /* the rest of one iteration of Trace's bounce loop — RC:488-538 */
-            bool endPath = false;
-            if (h.obj < 0) {
-                phase_mark<STATS>(st, PH_SKY);
-                const RT_CAS KArgs& c = cold_args();
-                if (c.useSky) pathLight = pathLight + transmittance * environment_light(c, rdir);
-                endPath = true;
-            } else {
-                /* resolve the winner: position, normal, material */
-                phase_mark<STATS>(st, PH_SHADE_HIT);
-                rt_f3 hpos, normal;
-                resolve_hit(a, rpos, rdir, h, hpos, normal);
-                const DMaterial mat = a.materials[h.obj];
-
-                /* The glass (RC:499-518) and opaque (RC:519-533) branches both draw
-                 * diffuseDir = normalize(normal + RandomDirection) — the costliest piece
-                 * (3 log, 3 cos, 4 sqrt).  It is hoisted so that all hit lanes execute it
-                 * together; each lane still consumes its random numbers in its branch's
-                 * order: opaque = [isSpecular, direction x6], glass = [direction x6, choice]. */
-                const bool isGlass = mat.flag == RT_MATERIAL_GLASS;
-                float uSpec = 0.0f;
-                if (!isGlass) uSpec = rt_random_value(&rng); /* RC:521 */
-                const rt_f3 diffuseDir = rt_normalize(normal + rand_direction(&rng)); /* RC:509 / RC:525 */
-                /* Both branches end in normalize(lerp(A, B, t)) of a direction pair: opaque (diffuseDir, reflect, smoothness x
-                 * isSpecular), glass either (diffuseDir, reflect, specularProbability) or (-diffuseDir, refract, smoothness).  The
-                 * reference normalises both glass candidates and keeps one (RC:511-516); only the kept one is observable, so the
-                 * branches just pick (A, B, t) and ONE lerp + normalize follows for all hit lanes. */
-                const rt_f3 specularDir = rt_reflect(rdir, normal); /* == the glass branch's reflectDir, RC:419-422 */
-                rt_f3 lerpA = diffuseDir, lerpB = specularDir;
-                float lerpT;
-                if (isGlass) {
-                    phase_mark<STATS>(st, PH_GLASS);
-                    if (h.backface) { /* RC:502 */
-                        rt_f3 e = ((-h.dst) * rt_v3(mat.absorption[0], mat.absorption[1], mat.absorption[2])) * mat.absorptionStrength;
-                        transmittance = transmittance * rt_v3(rt_exp(e.x), rt_exp(e.y), rt_exp(e.z));
-                    }
-                    float iorCurrent = h.backface ? mat.ior : 1.0f;
-                    float iorNext = h.backface ? 1.0f : mat.ior;
-                    const rt_f3 refractDir = refract_dir(rdir, normal, iorCurrent, iorNext);
-                    const float reflectWeight = reflectance(rdir, normal, iorCurrent, iorNext);
-                    const bool followReflection = rt_random_value(&rng) <= reflectWeight; /* RC:515 */
-                    lerpT = mat.specularProbability;
-                    if (!followReflection) {
-                        lerpA = -diffuseDir;
-                        lerpB = refractDir;
-                        lerpT = mat.smoothness;
-                    }
-                } else {
-                    const bool isSpecular = mat.specularProbability >= uSpec;
-                    lerpT = mat.smoothness * (isSpecular ? 1.0f : 0.0f);
-                    rt_f3 emitted = rt_v3(mat.emissionCol[0], mat.emissionCol[1], mat.emissionCol[2]) * mat.emissionStrength;
-                    pathLight = pathLight + emitted * transmittance;
-                    transmittance = transmittance * material_colour(mat, hpos, normal, isSpecular);
-                }
-                rdir = rt_normalize(rt_lerp3(lerpA, lerpB, lerpT));
-                rpos = isGlass ? hpos + (0.001f * normal) * rt_sign(rt_dot(normal, rdir)) : hpos + (normal * 0.001f);
-                /* RC:535-538 Russian roulette */
-                float p = rt_max(transmittance.x, rt_max(transmittance.y, transmittance.z));
-                if (rt_random_value(&rng) >= p) {
-                    endPath = true;
-                } else {
-                    transmittance = transmittance * rt_rcp(p);
-                    if (MANY) {
-                        const uint32_t b = extBase[(1 + a.extWords) * RT_WAVE] + 1u;
-                        extBase[(1 + a.extWords) * RT_WAVE] = b;
-                        if ((int)b > a.maxBounce) endPath = true;
-                    } else {
-                        bounce++;
-                        if (bounce > a.maxBounce) endPath = true; /* RC:485: i <= MaxBounceCount */
-                    }
-                }
-            }
-            if (endPath) {
-                PXF(PX_TIX) = PXF(PX_TIX) + pathLight.x; /* RC:578: totalIncomingLight += Trace(...) */
-                PXF(PX_TIY) = PXF(PX_TIY) + pathLight.y;
-                PXF(PX_TIZ) = PXF(PX_TIZ) + pathLight.z;
-                pathActive = false;
-            }
-        }
+        if constexpr (!POOL) shade_phase();
         } /* !laneDone */
+        if constexpr (POOL) {
+            pool_exchange<STATS>(a, s_lds, (uint32_t)a.poolCells, lane, pxu, PX_COLD(cold_args()), laneDone, pathActive, inTrav, rpos, rdir, transmittance, pathLight, rng, bounce, h, segments, st);
+            if (!laneDone) shade_phase();
+        }
     }
 
 #undef RT_SET_POOL
@@ -1204,12 +1376,12 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
 /* MANY: scenes with more than 64 models (two-level filter, candidate masks extended into LDS) — a separate
  * instantiation so that the common case keeps its registers */
 template <bool STATS, bool FLAT, bool MANY = false, bool HOT = false>
-__global__ void __launch_bounds__(HOT ? RT_WAVE * RT_MAX_WAVES_PER_GROUP : RT_WAVE, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : MANY ? RT_MIN_WAVES_PER_SIMD_MANY : RT_MIN_WAVES_PER_SIMD) rt_trace_kernel(const KArgs a)
+__global__ void __launch_bounds__(HOT ? RT_WAVE * (FLAT ? RT_MAX_WAVES_PER_GROUP_FLAT : RT_MAX_WAVES_PER_GROUP) : RT_WAVE, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : MANY ? RT_MIN_WAVES_PER_SIMD_MANY : RT_MIN_WAVES_PER_SIMD) rt_trace_kernel(const KArgs a)
 {
     trace_body<STATS, FLAT, MANY, HOT>(a);
 }
 template <bool STATS, bool FLAT, bool MANY = false, bool HOT = false>
-__global__ void __launch_bounds__(HOT ? RT_WAVE * RT_MAX_WAVES_PER_GROUP : RT_WAVE, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : MANY ? RT_MIN_WAVES_PER_SIMD_MANY : RT_MIN_WAVES_PER_SIMD) rt_trace_half_kernel(const KArgs a)
+__global__ void __launch_bounds__(HOT ? RT_WAVE * (FLAT ? RT_MAX_WAVES_PER_GROUP_FLAT : RT_MAX_WAVES_PER_GROUP) : RT_WAVE, FLAT ? RT_MIN_WAVES_PER_SIMD_FLAT : MANY ? RT_MIN_WAVES_PER_SIMD_MANY : RT_MIN_WAVES_PER_SIMD) rt_trace_half_kernel(const KArgs a)
 {
     trace_body<STATS, FLAT, MANY, HOT>(a);
 }
