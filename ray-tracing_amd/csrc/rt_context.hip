@@ -89,7 +89,7 @@ struct RtContext {
     int stackEntries = 1; /* deepest BVH of the scene = most entries a lane can push */
     int wavesPerGroup = 1; /* the BVH variants' workgroups: waves that share one LDS top-of-tree cache (plan_groups) */
     uint32_t hotUnits = 0; /* units [0, hotUnits) of the pair space are that cache's records */
-    int poolWaves = 1, poolCells = 0; /* the FLAT variant's workgroups: waves that share one LDS chain pool of 2 x poolCells cells (rt_kernels.h, pool_exchange); 0 cells = no pool */
+    int poolWaves = 1, poolCells = 0; /* the FLAT variant's workgroups: waves that share one LDS chain pool (rt_kernels.h, pool_exchange); poolCells = RT_POOL_CELLS or 0 = no pool */
     uint32_t travLimit = 1u << 20; /* traversal watchdog (rt_kernels.h, traverse): 64 x the steps one ray can take in this scene */
     bool haveScene = false;
     /* scene (host mirrors needed by rt_update_models) */
@@ -1275,7 +1275,7 @@ static int commit_scene(RtContext* ctx, const PreparedScene& ps, const RtContext
     ctx->nTris = ps.nTris;
     ctx->nPairs = (int)ps.nPairs;
     ctx->hTriBase = ps.lay.triBase;
-    ctx->stackEntries = ps.maxHeight;
+    ctx->stackEntries = ps.flat ? 0 : ps.maxHeight; /* (the FLAT variant pushes nothing: its LDS is pixel bookkeeping only) */
     ctx->flatScene = ps.flat;
     ctx->hotUnits = ps.flat ? 0u : ps.lay.hotUnits;
     {   /* one ray, one segment: every model once (a step each), every pair and every leaf of its tree at most once — and the same tree once
@@ -1288,18 +1288,15 @@ static int commit_scene(RtContext* ctx, const PreparedScene& ps, const RtContext
     ctx->wavesPerGroup = ctx->hotUnits ? ps.wavesPerGroup : 1;
     {   /* the FLAT variant's chain pool (rt_kernels.h, pool_exchange): 16-wave workgroups (two per CU at the variant's 8 waves per SIMD), two
          * queues of 64 cells of 128 bytes — 17 KB of the workgroup's 70 KB.  RT_POOL=0: single-wave workgroups without a pool (rounds 1-5);
-         * RT_POOL_WAVES / RT_POOL_CELLS (a power of two): A/B runs and tests */
-        int on = 1, waves = RT_MAX_WAVES_PER_GROUP_FLAT, cells = 64;
+         * RT_POOL_WAVES: A/B runs and tests */
+        int on = 1, waves = RT_MAX_WAVES_PER_GROUP_FLAT;
         if (const char* e = getenv("RT_POOL")) on = atoi(e);
         if (const char* e = getenv("RT_POOL_WAVES")) waves = atoi(e);
-        if (const char* e = getenv("RT_POOL_CELLS")) cells = atoi(e);
         if (waves < 1) waves = 1;
         if (waves > RT_MAX_WAVES_PER_GROUP_FLAT) waves = RT_MAX_WAVES_PER_GROUP_FLAT;
-        while (cells & (cells - 1)) cells &= cells - 1; /* round down to a power of two */
-        if (cells > 1024) cells = 1024;
-        const bool pooled = ps.flat && on && cells >= 2;
+        const bool pooled = ps.flat && on;
         ctx->poolWaves = pooled ? waves : 1;
-        ctx->poolCells = pooled ? cells : 0;
+        ctx->poolCells = pooled ? (int)RT_POOL_CELLS : 0;
     }
     ctx->hModels = ps.hModels;
     ctx->hRootCodes = ps.rootCodes;
@@ -1690,7 +1687,7 @@ static int choose_variant(RtContext* ctx, KArgs& a, LaunchPlan& plan, bool* many
     const size_t waveBytes = wave_lds_bytes(ctx->stackEntries, ctx->extWords) + coldBytes;
     /* the shared region in front of the waves' regions: the BVH variants' top-of-tree cache, or the FLAT variant's chain pool */
     const bool pooled = ctx->flatScene && ctx->poolCells > 0;
-    const uint32_t hotUnits = ctx->flatScene ? (pooled ? (uint32_t)(RT_POOL_DWORDS(ctx->poolCells) / 4) : 0u) : ctx->hotUnits;
+    const uint32_t hotUnits = ctx->flatScene ? (pooled ? (uint32_t)(RT_POOL_DWORDS / 4u) : 0u) : ctx->hotUnits;
     const int wpb = ctx->flatScene ? (pooled ? ctx->poolWaves : 1) : (hotUnits ? ctx->wavesPerGroup : 1);
     plan.wavesPerGroup = wpb;
     plan.blockThreads = RT_WAVE * wpb;

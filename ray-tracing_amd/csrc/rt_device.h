@@ -34,12 +34,14 @@
 #define RT_N_PHASES 12
 #define RT_MAX_WAVES_PER_GROUP 12      /* the BVH trace kernels' workgroups: up to 12 waves share one LDS top-of-tree cache (rt_kernels.h) */
 /* the FLAT trace kernel's workgroups (round 6): up to 16 waves share one LDS CHAIN POOL (rt_kernels.h, pool_exchange): two queues (chains
- * waiting for the sky phase / for the shade phase) of poolCells cells each; a cell = RT_POOL_QUADS x 16 bytes of chain state.
- * LDS of a workgroup: [header: RT_POOL_HEADER_DWORDS][seq: 2 x poolCells dwords][payload: 2 x RT_POOL_QUADS x poolCells x 16 B][wave regions] */
+ * waiting for the sky phase / for the shade phase) of RT_POOL_CELLS cells each (a power of two; 32 measured 10 % slower than 64 on the headline
+ * scene, 128 the same as 64: profiles/r06_chain_pool.txt); a cell = RT_POOL_QUADS x 16 bytes of chain state.
+ * LDS of a workgroup: [header: RT_POOL_HEADER_DWORDS][seq: 2 x RT_POOL_CELLS dwords][payload: 2 x RT_POOL_QUADS x RT_POOL_CELLS x 16 B][wave regions] */
 #define RT_MAX_WAVES_PER_GROUP_FLAT 16
-#define RT_POOL_QUADS 8
-#define RT_POOL_HEADER_DWORDS 16
-#define RT_POOL_DWORDS(cells) (RT_POOL_HEADER_DWORDS + 2 * (cells) + 2 * RT_POOL_QUADS * (cells) * 4)
+#define RT_POOL_CELLS 64u
+#define RT_POOL_QUADS 8u
+#define RT_POOL_HEADER_DWORDS 16u
+#define RT_POOL_DWORDS (RT_POOL_HEADER_DWORDS + 2u * RT_POOL_CELLS + 2u * RT_POOL_QUADS * RT_POOL_CELLS * 4u)
 /* bytes of a wave's record in KArgs::pxCold: two float4 per lane (+ the traversal stack in the RT_GLOBAL_STACK experiment) */
 #define RT_COLD_STRIDE_BYTES (2 * RT_WAVE * 16)
 #define RT_COUNTER_FIELDS (8 + 2 * RT_N_PHASES + 4) /* ... + hot-cache steps, node-uniform steps (>= 48 lanes, >= 3/4 of the active lanes) */
@@ -142,7 +144,7 @@ struct KArgs {
     /* the BVH variants' workgroups (round 6): wavesPerGroup waves, LDS = [hot cache: hotUnits x 16 B][wave 0's region][wave 1's] ...;
      * units [0, hotUnits) of the pair space are the top-of-tree records the workgroup copies into LDS when it starts (rt_layout.h) */
     int32_t wavesPerGroup, hotUnits, waveLdsDwords;
-    int32_t poolCells;           /* the FLAT variant's chain pool: cells per queue (a power of two), 0 = single-wave workgroups without a pool;
+    int32_t poolCells;           /* the FLAT variant's chain pool: RT_POOL_CELLS, or 0 = single-wave workgroups without a pool;
                                   * hotUnits then = the pool region's size in 16-byte units (the wave regions start behind it) */
     uint32_t travLimit;          /* traversal watchdog: iterations of one traverse() call no validated scene can reach (rt_kernels.h) */
     /* uniforms (RtParams) */

@@ -819,124 +819,122 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 #define RT_POOL_SPIN_LIMIT (1u << 16)
 #endif
 #define RT_POOL_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define RT_POOL_LOAD_ACQ(p) __hip_atomic_load((p), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define RT_POOL_STORE_REL(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define RT_POOL_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define RT_RFL(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))
 template <bool STATS>
-__device__ __forceinline__ void pool_exchange(const KArgs& a, uint32_t* const pool, const uint32_t C, const int lane, uint32_t* const pxu, float4* const cold,
+__device__ __forceinline__ void pool_exchange(const KArgs& a, uint32_t* const pool, const int lane, uint32_t* const pxu, float4* const cold,
                                               bool& laneDone, bool& pathActive, bool& inTrav, rt_f3& rpos, rt_f3& rdir, rt_f3& transmittance, rt_f3& pathLight,
                                               uint32_t& rng, int& bounce, SceneHit& h, const uint32_t segments, Stats& st)
 {
+    /* (the geometry is a compile-time constant: every mask and offset below is an immediate.  The exchange runs once per wave iteration and is
+     * mostly scalar bookkeeping — the scalar unit is shared by the CU's waves, so its instruction count is what the exchange costs) */
+    constexpr uint32_t C = RT_POOL_CELLS;
     const bool wantSky = !laneDone && inTrav && h.obj < 0;
     const bool wantShade = !laneDone && inTrav && h.obj >= 0;
     const unsigned long long mS = __ballot(wantSky), mH = __ballot(wantShade);
-    unsigned long long mE = __ballot(laneDone);
+    const unsigned long long mE = __ballot(laneDone);
     const int nS = __popcll(mS), nH = __popcll(mH);
-    /* queue 0 = sky, queue 1 = shade; header dwords: head0 tail0 head1 tail1 (every lane reads the same address: an LDS broadcast) */
-    const int qS = (int)(RT_RFL(RT_POOL_LOAD(pool + 1)) - RT_RFL(RT_POOL_LOAD(pool + 0)));
-    const int qH = (int)(RT_RFL(RT_POOL_LOAD(pool + 3)) - RT_RFL(RT_POOL_LOAD(pool + 2)));
+    if (mE == 0ull && (nS == 0 || nH == 0)) return; /* every lane holds a chain and they all want the same phase: nothing to hand over or take */
+    /* Header, queue 0 = sky, queue 1 = shade: dwords (head0, tail1, head1, tail0) — the two counters ONE exchange moves lie in one 64-bit word:
+     * target shade = deposit into sky (tail0) + withdraw from shade (head1) = dwords 2..3; target sky = (head0, tail1) = dwords 0..1.
+     * ONE compare-and-swap of that word by the wave's first lane reserves both ranges; if another wave moved either counter since the header
+     * was read the swap fails and this iteration goes without an exchange (the phases below handle any mix of lanes). */
+    asm volatile("" ::: "memory");
+    const uint4 hdr = *reinterpret_cast<const uint4*>(pool); /* one 16-byte read, the same address in every lane */
+    const uint32_t head0 = RT_RFL(hdr.x), tail1 = RT_RFL(hdr.y), head1 = RT_RFL(hdr.z), tail0 = RT_RFL(hdr.w);
+    const int qS = (int)(tail0 - head0), qH = (int)(tail1 - head1);
     const bool tgtShade = nH + qH >= nS + qS;
-    const unsigned long long mOther = tgtShade ? mS : mH;
-    const int nOther = __popcll(mOther);
-    if (nOther == 0 && (mE == 0ull || (tgtShade ? qH : qS) <= 0)) return; /* nothing to hand over, nobody to take anything */
-    const uint32_t qo = tgtShade ? 0u : 1u, qt = 1u - qo;
+    /* a stale head only underestimates the room, a stale tail only the chains to take */
+    const int nOther = tgtShade ? nS : nH;
+    const int room = (int)C - (tgtShade ? qS : qH);
+    int nDep = nOther < room ? nOther : room;
+    nDep = nDep > 0 ? nDep : 0;
+    const int empties = __popcll(mE) + nDep;
+    const int avail = tgtShade ? qH : qS;
+    int nW = empties < avail ? empties : avail;
+    nW = nW > 0 ? nW : 0;
+    if ((nDep | nW) == 0) return;
+    const uint32_t wBase = tgtShade ? head1 : head0, dBase = tgtShade ? tail0 : tail1;
+    {
+        const unsigned long long expect = (unsigned long long)wBase | ((unsigned long long)dBase << 32);
+        const unsigned long long want = (unsigned long long)(wBase + (uint32_t)nW) | ((unsigned long long)(dBase + (uint32_t)nDep) << 32);
+        unsigned long long old = expect;
+        if (lane == 0) old = atomicCAS(reinterpret_cast<unsigned long long*>(pool + (tgtShade ? 2 : 0)), expect, want);
+        if (RT_RFL((uint32_t)old) != wBase || RT_RFL((uint32_t)(old >> 32)) != dBase) return;
+    }
     uint32_t* const seq = pool + RT_POOL_HEADER_DWORDS;
     float4* const payload = reinterpret_cast<float4*>(pool + RT_POOL_HEADER_DWORDS + 2u * C);
-    bool broken = false;
-    /* ---- deposit the lanes of the other phase */
-    if (nOther) {
-        uint32_t* const headp = pool + 2u * qo;
-        uint32_t* const tailp = headp + 1;
-        uint32_t base = 0u;
-        int nDep = 0;
-        for (int tries = 0; tries < 64; tries++) { /* wave-uniform; a failed compare-and-swap means another wave moved the tail: look again */
-            const uint32_t hh = RT_RFL(RT_POOL_LOAD(headp)), tt = RT_RFL(RT_POOL_LOAD(tailp)); /* head first: the room is never overestimated */
-            const int room = (int)C - (int)(tt - hh);
-            const int n = nOther < room ? nOther : room;
-            if (n <= 0) break;
-            uint32_t old = tt;
-            if (lane == 0) old = atomicCAS(tailp, tt, tt + (uint32_t)n);
-            old = RT_RFL(old);
-            if (old == tt) { base = tt; nDep = n; break; }
-        }
-        if (nDep) {
-            const int rank = __popcll(mOther & ((1ull << lane) - 1ull));
-            if ((tgtShade ? wantSky : wantShade) && rank < nDep) {
-                const uint32_t pos = base + (uint32_t)rank, cell = pos & (C - 1u);
-                uint32_t* const sp = seq + qo * C + cell;
-                uint32_t spins = 0u;
-                while (RT_POOL_LOAD_ACQ(sp) != pos) {
-                    if (++spins > RT_POOL_SPIN_LIMIT) { broken = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
+    const uint32_t qo = tgtShade ? 0u : 1u, qt = 1u - qo;
+    /* who does what: the first nDep lanes of the other phase deposit; the first nW lanes that are empty afterwards withdraw (a lane may do both);
+     * ranks through v_mbcnt (bits of the mask below this lane) */
+    const unsigned long long mOther = tgtShade ? mS : mH;
+    const uint32_t rankD = __builtin_amdgcn_mbcnt_hi((uint32_t)(mOther >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mOther, 0u));
+    const bool deposits = (tgtShade ? wantSky : wantShade) && (int)rankD < nDep;
+    const unsigned long long mEmptyAfter = mE | __ballot(deposits);
+    const uint32_t rankW = __builtin_amdgcn_mbcnt_hi((uint32_t)(mEmptyAfter >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mEmptyAfter, 0u));
+    const bool withdraws = (laneDone || deposits) && (int)rankW < nW;
+    const uint32_t posD = dBase + rankD, cellD = posD & (C - 1u);
+    const uint32_t posW = wBase + rankW, cellW = posW & (C - 1u);
+    uint32_t* const spD = seq + qo * C + cellD;
+    uint32_t* const spW = seq + qt * C + cellW;
+    /* both cells' sequence words in one go (every lane reads both; lanes without the role compare against what they read): the deposit's must say
+     * "free for posD" (the reader of the previous lap is done), the withdrawal's "written for posW".  Almost always true at once. */
+    {
+        uint32_t sD = RT_POOL_LOAD(spD), sW = RT_POOL_LOAD(spW);
+        if (__ballot((deposits && sD != posD) || (withdraws && sW != posW + 1u))) { /* rare: a writer / reader of the cell is in the middle of its copy */
+            uint32_t spins = 0u;
+            bool waiting = true;
+            while (waiting) {
+                __builtin_amdgcn_s_sleep(1);
+                sD = RT_POOL_LOAD(spD);
+                sW = RT_POOL_LOAD(spW);
+                waiting = (deposits && sD != posD) || (withdraws && sW != posW + 1u);
+                if (++spins > RT_POOL_SPIN_LIMIT) { /* a broken pool costs a wrong image that says so (watchdog counter), never a hung device */
+                    if (waiting) atomicAdd(a.counters + 7, 1ull);
+                    waiting = false;
                 }
-                float4* const q = payload + (size_t)(qo * RT_POOL_QUADS) * C + cell; /* quad j of the cell: q[j * C] */
-                const float4 rec1 = cold[RT_WAVE];
-                q[0 * C] = make_float4(rpos.x, rpos.y, rpos.z, __uint_as_float(rng));
-                q[1 * C] = make_float4(rdir.x, rdir.y, rdir.z, __uint_as_float((uint32_t)bounce));
-                q[2 * C] = make_float4(transmittance.x, transmittance.y, transmittance.z, h.dst);
-                q[3 * C] = make_float4(pathLight.x, pathLight.y, pathLight.z, __uint_as_float((uint32_t)h.obj));
-                q[4 * C] = make_float4(__uint_as_float((uint32_t)h.tri), h.u, h.v, h.det);
-                q[5 * C] = make_float4(__uint_as_float(pxu[0 * RT_WAVE]), __uint_as_float(pxu[1 * RT_WAVE]), __uint_as_float(pxu[2 * RT_WAVE]), __uint_as_float(pxu[3 * RT_WAVE]));
-                q[6 * C] = cold[0];
-                /* the record's second word = `segments` of the LANE when the pixel was set up (tile cost = the chain's segments so far): it travels as the
-                 * chain's own count and is re-based on the taker's counter; the spare fourth word carries the hit's backface flag */
-                q[7 * C] = make_float4(rec1.x, __uint_as_float(segments - __float_as_uint(rec1.y)), rec1.z, __uint_as_float(h.backface ? 1u : 0u));
-                RT_POOL_STORE_REL(sp, pos + 1u);
-                laneDone = true;
-                inTrav = false;
-                pathActive = false;
-                if (STATS) st.hotSteps++;
-            }
-            mE = __ballot(laneDone);
-        }
-    }
-    /* ---- withdraw chains of the target phase into the empty lanes */
-    if (mE) {
-        const int nWant = __popcll(mE);
-        uint32_t* const headp = pool + 2u * qt;
-        uint32_t* const tailp = headp + 1;
-        uint32_t base = 0u;
-        int nW = 0;
-        for (int tries = 0; tries < 64; tries++) {
-            const uint32_t hh = RT_RFL(RT_POOL_LOAD(headp)), tt = RT_RFL(RT_POOL_LOAD(tailp));
-            const int avail = (int)(tt - hh); /* reserved by their writers, possibly still being written: the sequence word says when */
-            const int n = nWant < avail ? nWant : avail;
-            if (n <= 0) break;
-            uint32_t old = hh;
-            if (lane == 0) old = atomicCAS(headp, hh, hh + (uint32_t)n);
-            old = RT_RFL(old);
-            if (old == hh) { base = hh; nW = n; break; }
-        }
-        if (nW) {
-            const int rank = __popcll(mE & ((1ull << lane) - 1ull));
-            if (laneDone && rank < nW) {
-                const uint32_t pos = base + (uint32_t)rank, cell = pos & (C - 1u);
-                uint32_t* const sp = seq + qt * C + cell;
-                uint32_t spins = 0u;
-                while (RT_POOL_LOAD_ACQ(sp) != pos + 1u) {
-                    if (++spins > RT_POOL_SPIN_LIMIT) { broken = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                const float4* const q = payload + (size_t)(qt * RT_POOL_QUADS) * C + cell;
-                const float4 q0 = q[0 * C], q1 = q[1 * C], q2 = q[2 * C], q3 = q[3 * C], q4 = q[4 * C], q5 = q[5 * C], q6 = q[6 * C], q7 = q[7 * C];
-                RT_POOL_STORE_REL(sp, pos + C);
-                rpos = rt_v3(q0.x, q0.y, q0.z); rng = __float_as_uint(q0.w);
-                rdir = rt_v3(q1.x, q1.y, q1.z); bounce = (int)__float_as_uint(q1.w);
-                transmittance = rt_v3(q2.x, q2.y, q2.z); h.dst = q2.w;
-                pathLight = rt_v3(q3.x, q3.y, q3.z); h.obj = (int)__float_as_uint(q3.w);
-                h.tri = (int)__float_as_uint(q4.x); h.u = q4.y; h.v = q4.z; h.det = q4.w;
-                pxu[0 * RT_WAVE] = __float_as_uint(q5.x); pxu[1 * RT_WAVE] = __float_as_uint(q5.y); pxu[2 * RT_WAVE] = __float_as_uint(q5.z); pxu[3 * RT_WAVE] = __float_as_uint(q5.w);
-                cold[0] = q6;
-                cold[RT_WAVE] = make_float4(q7.x, __uint_as_float(segments - __float_as_uint(q7.y)), q7.z, 0.0f);
-                h.backface = __float_as_uint(q7.w) != 0u;
-                laneDone = false;
-                inTrav = true;
-                pathActive = true;
             }
         }
     }
-    if (__ballot(broken)) { /* wave-uniform */
-        if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) atomicAdd(a.counters + 7, 1ull); /* (the lane index recomputed: this path must not keep a register alive) */
+    asm volatile("" ::: "memory"); /* the payload accesses below stay below the sequence reads (LDS executes a wave's instructions in order) */
+    if (deposits) {
+        float4* const q = payload + qo * (RT_POOL_QUADS * C) + cellD; /* quad j of the cell: q[j * C] */
+        const float4 rec1 = cold[RT_WAVE];
+        q[0 * C] = make_float4(rpos.x, rpos.y, rpos.z, __uint_as_float(rng));
+        q[1 * C] = make_float4(rdir.x, rdir.y, rdir.z, __uint_as_float((uint32_t)bounce));
+        q[2 * C] = make_float4(transmittance.x, transmittance.y, transmittance.z, h.dst);
+        q[3 * C] = make_float4(pathLight.x, pathLight.y, pathLight.z, __uint_as_float((uint32_t)h.obj));
+        q[4 * C] = make_float4(__uint_as_float((uint32_t)h.tri), h.u, h.v, h.det);
+        q[5 * C] = make_float4(__uint_as_float(pxu[0 * RT_WAVE]), __uint_as_float(pxu[1 * RT_WAVE]), __uint_as_float(pxu[2 * RT_WAVE]), __uint_as_float(pxu[3 * RT_WAVE]));
+        q[6 * C] = cold[0];
+        /* the record's second word = `segments` of the LANE when the pixel was set up (tile cost = the chain's segments so far): it travels as the
+         * chain's own count and is re-based on the taker's counter; the spare fourth word carries the hit's backface flag */
+        q[7 * C] = make_float4(rec1.x, __uint_as_float(segments - __float_as_uint(rec1.y)), rec1.z, __uint_as_float(h.backface ? 1u : 0u));
+        /* published after the payload: a wave's LDS instructions execute in order, so no wait is needed between them — only the compiler must keep the order */
+        asm volatile("" ::: "memory");
+        RT_POOL_STORE(spD, posD + 1u);
+        laneDone = true;
+        inTrav = false;
+        pathActive = false;
+        if (STATS) st.hotSteps++;
+    }
+    if (withdraws) {
+        const float4* const q = payload + qt * (RT_POOL_QUADS * C) + cellW;
+        const float4 q0 = q[0 * C], q1 = q[1 * C], q2 = q[2 * C], q3 = q[3 * C], q4 = q[4 * C], q5 = q[5 * C], q6 = q[6 * C], q7 = q[7 * C];
+        asm volatile("" ::: "memory");
+        RT_POOL_STORE(spW, posW + C); /* behind the reads in the wave's LDS order: the cell is free for the next lap */
+        rpos = rt_v3(q0.x, q0.y, q0.z); rng = __float_as_uint(q0.w);
+        rdir = rt_v3(q1.x, q1.y, q1.z); bounce = (int)__float_as_uint(q1.w);
+        transmittance = rt_v3(q2.x, q2.y, q2.z); h.dst = q2.w;
+        pathLight = rt_v3(q3.x, q3.y, q3.z); h.obj = (int)__float_as_uint(q3.w);
+        h.tri = (int)__float_as_uint(q4.x); h.u = q4.y; h.v = q4.z; h.det = q4.w;
+        pxu[0 * RT_WAVE] = __float_as_uint(q5.x); pxu[1 * RT_WAVE] = __float_as_uint(q5.y); pxu[2 * RT_WAVE] = __float_as_uint(q5.z); pxu[3 * RT_WAVE] = __float_as_uint(q5.w);
+        cold[0] = q6;
+        cold[RT_WAVE] = make_float4(q7.x, __uint_as_float(segments - __float_as_uint(q7.y)), q7.z, 0.0f);
+        h.backface = __float_as_uint(q7.w) != 0u;
+        laneDone = false;
+        inTrav = true;
+        pathActive = true;
     }
 }
 
@@ -970,8 +968,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
     const RT_LDS char* const hotLds = (const RT_LDS char*)s_lds;
     if (POOL) {
         /* both queues empty: head = tail = 0, cell c free for position c (pool_exchange) */
-        const uint32_t C = (uint32_t)a.poolCells;
-        for (uint32_t i = threadIdx.x; i < RT_POOL_HEADER_DWORDS + 2u * C; i += blockDim.x) s_lds[i] = i < RT_POOL_HEADER_DWORDS ? 0u : ((i - RT_POOL_HEADER_DWORDS) & (C - 1u));
+        for (uint32_t i = threadIdx.x; i < RT_POOL_HEADER_DWORDS + 2u * RT_POOL_CELLS; i += blockDim.x) s_lds[i] = i < RT_POOL_HEADER_DWORDS ? 0u : ((i - RT_POOL_HEADER_DWORDS) & (RT_POOL_CELLS - 1u));
         __syncthreads();
     }
     if (HOT && !FLAT && hotUnits) {
@@ -1131,7 +1128,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
         if (idle == ~0ull) { /* no lane holds a chain and the queue has no pixel left */
             if (!POOL) break;
             /* ... a wave of a pooled workgroup stays while a queue of the pool holds (or is being handed) a chain: whoever is alive takes it */
-            if (RT_RFL(RT_POOL_LOAD(s_lds + 0)) == RT_RFL(RT_POOL_LOAD(s_lds + 1)) && RT_RFL(RT_POOL_LOAD(s_lds + 2)) == RT_RFL(RT_POOL_LOAD(s_lds + 3))) break;
+            if (RT_RFL(RT_POOL_LOAD(s_lds + 0)) == RT_RFL(RT_POOL_LOAD(s_lds + 3)) && RT_RFL(RT_POOL_LOAD(s_lds + 2)) == RT_RFL(RT_POOL_LOAD(s_lds + 1))) break; /* (head0, tail1, head1, tail0) */
         }
         /* the second half of an iteration — the rest of one iteration of Trace's bounce loop for the lanes whose intersection is complete —
          * as a callable: the pooled FLAT variant runs the chain exchange between the halves with every lane of the wave present */
@@ -1324,7 +1321,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
         if constexpr (!POOL) shade_phase();
         } /* !laneDone */
         if constexpr (POOL) {
-            pool_exchange<STATS>(a, s_lds, (uint32_t)a.poolCells, lane, pxu, PX_COLD(cold_args()), laneDone, pathActive, inTrav, rpos, rdir, transmittance, pathLight, rng, bounce, h, segments, st);
+            pool_exchange<STATS>(a, s_lds, lane, pxu, PX_COLD(cold_args()), laneDone, pathActive, inTrav, rpos, rdir, transmittance, pathLight, rng, bounce, h, segments, st);
             if (!laneDone) shade_phase();
         }
     }
