@@ -1686,7 +1686,11 @@ static int choose_variant(RtContext* ctx, KArgs& a, LaunchPlan& plan, bool* many
      * a workgroup of the BVH variants: the top-of-tree cache, then its waves' regions (plan_groups) */
     const size_t waveBytes = wave_lds_bytes(ctx->stackEntries, ctx->extWords) + coldBytes;
     /* the shared region in front of the waves' regions: the BVH variants' top-of-tree cache, or the FLAT variant's chain pool */
-    const bool pooled = ctx->flatScene && ctx->poolCells > 0;
+    /* ... for launches with enough work: a pooled workgroup is 16 persistent waves that leave together, and a launch with a few items per wave is
+     * all tail (config 1, 256 x 256: + 11 % with the pool) — at least RT_POOL_MIN_ITEMS (tile, frame) pairs per wave the chip keeps resident */
+    static const int poolMinItems = getenv("RT_POOL_MIN_ITEMS") ? atoi(getenv("RT_POOL_MIN_ITEMS")) : 4;
+    const bool pooled = ctx->flatScene && ctx->poolCells > 0 &&
+                        (long long)a.tilesX * a.tilesY * (a.nFrames > 0 ? a.nFrames : 1) >= (long long)poolMinItems * ctx->numCUs * 4 * RT_MIN_WAVES_PER_SIMD_FLAT;
     const uint32_t hotUnits = ctx->flatScene ? (pooled ? (uint32_t)(RT_POOL_DWORDS / 4u) : 0u) : ctx->hotUnits;
     const int wpb = ctx->flatScene ? (pooled ? ctx->poolWaves : 1) : (hotUnits ? ctx->wavesPerGroup : 1);
     plan.wavesPerGroup = wpb;
