@@ -625,8 +625,19 @@ def main():
     accumulated[0] += args.steps
     stats = tracer.counters()
     lds_cache = None
+    chain_pool = None
     try:   # BVH scenes: how many inner steps (lane-steps) the LDS top-of-tree cache served in the replayed K frames
         ph = tracer.phase_profile()
+        if not ph["inner"][1] and ph["loop"][0]:
+            # scenes without trees (the FLAT kernel): chains handed from wave to wave through the workgroup's LDS pool, and what that does to the two
+            # exclusive phases behind the intersection (wave-level executions and the lanes active in them, STATS instantiation, the timed frames)
+            util = lambda k: (ph[k][1] / (64.0 * ph[k][0])) if ph[k][0] else None
+            chain_pool = {"chains_deposited": ph["inner_from_lds_cache"][0], "wave_iterations": ph["loop"][0],
+                          "deposits_per_wave_iteration": ph["inner_from_lds_cache"][0] / ph["loop"][0],
+                          "lane_util_sky": util("sky"), "lane_util_shade": util("shade_hit"), "lane_util_raygen": util("raygen"),
+                          "what": "the FLAT kernel's workgroups (16 waves) share two LDS queues of pixel chains waiting for the sky / for the shade phase: a wave "
+                                  "deposits the lanes of its minority phase and withdraws chains of its majority phase (rt_kernels.h, pool_exchange); 0 deposits = "
+                                  "single-wave workgroups (RT_POOL=0, or a launch with too few items per wave)"}
         if ph["inner"][1]:
             lds_cache = {"inner_lane_steps": ph["inner"][1], "served_from_lds": ph["inner_from_lds_cache"][0],
                          "fraction": ph["inner_from_lds_cache"][0] / ph["inner"][1],
@@ -817,6 +828,7 @@ def main():
             "value_fused_launches_one_stream": (launch_segments / (launch_ms * 1e-3) / 1e6) if launch_ms else None,
             "batched_api": batched,
             "lds_top_of_tree_cache": lds_cache,
+            "chain_pool": chain_pool,
             "scene_load": scene_load,
             "parity": parity if parity is not None else "checked at N=1 (pytest -m gpu and the N=1 bench line)",
             "roofline": roof,

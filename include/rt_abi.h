@@ -435,7 +435,9 @@ void rt_debug_layout_free(RtLayoutDump* dump);
  * 11 pixel refill). n must be >= 24; if n >= 25, out[24] = number of times the conservative
  * world-space root filter rejected a model the exact root step would have entered (must be 0);
  * if n >= 28 (round 6), in lane-steps of the inner phase: out[25] = served by the LDS top-of-tree cache,
- * out[26] = taken while >= 48 lanes of the wave stood on one node, out[27] = while >= 3/4 of >= 16 active lanes did. */
+ * out[26] = taken while >= 48 lanes of the wave stood on one node, out[27] = while >= 3/4 of >= 16 active lanes did;
+ * scenes without trees (every model a single leaf): out[25] = pixel chains handed from one wave to another through the
+ * workgroup's LDS chain pool (deposits; rt_kernels.h, pool_exchange), out[26] = out[27] = 0. */
 int rt_debug_phase_profile(RtContext* ctx, uint64_t* out, int n);
 
 /* Frames the context would put into one fused launch right now (16 ... 64: a budget that follows the measured frame time, see

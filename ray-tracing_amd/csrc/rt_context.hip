@@ -89,6 +89,7 @@ struct RtContext {
     int stackEntries = 1; /* deepest BVH of the scene = most entries a lane can push */
     int wavesPerGroup = 1; /* the BVH variants' workgroups: waves that share one LDS top-of-tree cache (plan_groups) */
     uint32_t hotUnits = 0; /* units [0, hotUnits) of the pair space are that cache's records */
+    int poolMinItems = 4; /* RT_POOL_MIN_ITEMS: (tile, frame) items per resident wave a launch needs to run as pooled workgroups (choose_variant) */
     int poolWaves = 1, poolCells = 0; /* the FLAT variant's workgroups: waves that share one LDS chain pool (rt_kernels.h, pool_exchange); poolCells = RT_POOL_CELLS or 0 = no pool */
     uint32_t travLimit = 1u << 20; /* traversal watchdog (rt_kernels.h, traverse): 64 x the steps one ray can take in this scene */
     bool haveScene = false;
@@ -359,6 +360,7 @@ int rt_create(int device_id, RtContext** out)
     }
     memset(&ctx->params, 0, sizeof(ctx->params));
     if (const char* g = getenv("RT_GRID")) ctx->gridOverride = atoi(g); /* tuning hook */
+    if (const char* g = getenv("RT_POOL_MIN_ITEMS")) ctx->poolMinItems = atoi(g);
     if (getenv("RT_VERBOSE")) ctx->verbose = true;
     if (const char* f = getenv("RT_FUSE_FRAMES")) ctx->fuseFrames = atoi(f) != 0;
     if (const char* l = getenv("RT_LPT")) ctx->lptEnabled = atoi(l) != 0;
@@ -1688,9 +1690,8 @@ static int choose_variant(RtContext* ctx, KArgs& a, LaunchPlan& plan, bool* many
     /* the shared region in front of the waves' regions: the BVH variants' top-of-tree cache, or the FLAT variant's chain pool */
     /* ... for launches with enough work: a pooled workgroup is 16 persistent waves that leave together, and a launch with a few items per wave is
      * all tail (config 1, 256 x 256: + 11 % with the pool) — at least RT_POOL_MIN_ITEMS (tile, frame) pairs per wave the chip keeps resident */
-    static const int poolMinItems = getenv("RT_POOL_MIN_ITEMS") ? atoi(getenv("RT_POOL_MIN_ITEMS")) : 4;
     const bool pooled = ctx->flatScene && ctx->poolCells > 0 &&
-                        (long long)a.tilesX * a.tilesY * (a.nFrames > 0 ? a.nFrames : 1) >= (long long)poolMinItems * ctx->numCUs * 4 * RT_MIN_WAVES_PER_SIMD_FLAT;
+                        (long long)a.tilesX * a.tilesY * (a.nFrames > 0 ? a.nFrames : 1) >= (long long)ctx->poolMinItems * ctx->numCUs * 4 * RT_MIN_WAVES_PER_SIMD_FLAT;
     const uint32_t hotUnits = ctx->flatScene ? (pooled ? (uint32_t)(RT_POOL_DWORDS / 4u) : 0u) : ctx->hotUnits;
     const int wpb = ctx->flatScene ? (pooled ? ctx->poolWaves : 1) : (hotUnits ? ctx->wavesPerGroup : 1);
     plan.wavesPerGroup = wpb;

@@ -46,9 +46,14 @@ if os.environ.get("RT_PHASES"):
         c = tr.counters(); ph = tr.phase_profile()
         print(f"config {cfg} phase profile ({nph} frame(s) in one launch, {c['segments']} segments):")
         inner_lanes = ph["inner"][1] or 1
+        if not ph["inner"][1]:   # no trees: the FLAT kernel, whose counter in that slot is the chain pool's
+            v = ph.pop("inner_from_lds_cache", (0, 0))[0]
+            print(f"   chains handed over through the workgroup's LDS pool: {v} = {v / max(1, ph['loop'][0]):.1f} per wave iteration")
+            ph.pop("inner_on_one_node_48_lanes", None); ph.pop("inner_on_one_node_3_of_4_active", None)
         for key, label in (("inner_from_lds_cache", "inner steps served by the LDS top-of-tree cache"),
                            ("inner_on_one_node_48_lanes", "inner steps with >= 48 lanes of the wave on ONE node"),
                            ("inner_on_one_node_3_of_4_active", "inner steps with >= 3/4 of >= 16 active lanes on ONE node")):
+            if key not in ph: continue
             v = ph.pop(key, (0, 0))[0]
             print(f"   {label}: {v} lane-steps = {v / inner_lanes:.3f} of all inner lane-steps")
         for k, (e, l) in ph.items():
