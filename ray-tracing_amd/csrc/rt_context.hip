@@ -1957,6 +1957,8 @@ static int enqueue_trace(RtContext* ctx, KArgs& a, const LaunchPlan& plan, int t
             if (group > nFrames) group = nFrames;
         }
         a.frameGroup = group;
+        a.frameGroupShift = 0;
+        while ((2 << a.frameGroupShift) <= group) a.frameGroupShift++;
         a.frameGroups = staged ? (nFrames + group - 1) / group : 1;
         const long long items = (long long)partTiles * a.frameGroups;
         /* the grid: workgroups of wavesPerGroup persistent waves each — as many as the chip keeps resident, never more waves than there

@@ -168,6 +168,7 @@ struct KArgs {
     int32_t launchItems;         /* queue positions of this launch: launchTiles, or launchTiles * frameGroups (tile, frame group) items */
     float4* pxCold;              /* per-wave pixel records of this launch: [grid][64 lanes][2] float4 (rt_kernels.h, PX_COLD) */
     int32_t frameGroup;          /* consecutive frames per item (>= 1) */
+    int32_t frameGroupShift;     /* floor(log2(frameGroup)): the tile cost's per-frame figure without a division */
     int32_t frameGroups;         /* ceil(nFrames / frameGroup) */
     float* staging;              /* nFrames > 1: [frame - frame0][stagingStride pixels] RGBA colours awaiting rt_accumulate_kernel */
     uint32_t stagingStride;

@@ -918,8 +918,8 @@ __device__ __forceinline__ void pool_exchange(const KArgs& a, uint32_t* const po
         q[5 * C] = make_float4(__uint_as_float(pxu[0 * RT_WAVE]), __uint_as_float(pxu[1 * RT_WAVE]), __uint_as_float(pxu[2 * RT_WAVE]), __uint_as_float(pxu[3 * RT_WAVE]));
         q[6 * C] = cold[0];
         /* the record's second word = `segments` of the LANE when the pixel was set up (tile cost = the chain's segments so far): it travels as the
-         * chain's own count and is re-based on the taker's counter; the spare fourth word carries the hit's backface flag */
-        q[7 * C] = make_float4(rec1.x, __uint_as_float(segments - __float_as_uint(rec1.y)), rec1.z, __uint_as_float(h.backface ? 1u : 0u));
+         * chain's own count and is re-based on the taker's counter; bit 31 of the frame word carries the hit's backface flag */
+        q[7 * C] = make_float4(rec1.x, __uint_as_float(segments - __float_as_uint(rec1.y)), __uint_as_float(__float_as_uint(rec1.z) | (h.backface ? 0x80000000u : 0u)), rec1.w);
         /* published after the payload: a wave's LDS instructions execute in order, so no wait is needed between them — only the compiler must keep the order */
         asm volatile("" ::: "memory");
         RT_POOL_STORE(spD, posD + 1u);
@@ -940,8 +940,8 @@ __device__ __forceinline__ void pool_exchange(const KArgs& a, uint32_t* const po
         h.tri = (int)__float_as_uint(q4.x); h.u = q4.y; h.v = q4.z; h.det = q4.w;
         pxu[0 * RT_WAVE] = __float_as_uint(q5.x); pxu[1 * RT_WAVE] = __float_as_uint(q5.y); pxu[2 * RT_WAVE] = __float_as_uint(q5.z); pxu[3 * RT_WAVE] = __float_as_uint(q5.w);
         cold[0] = q6;
-        cold[RT_WAVE] = make_float4(q7.x, __uint_as_float(segments - __float_as_uint(q7.y)), q7.z, 0.0f);
-        h.backface = __float_as_uint(q7.w) != 0u;
+        cold[RT_WAVE] = make_float4(q7.x, __uint_as_float(segments - __float_as_uint(q7.y)), __uint_as_float(__float_as_uint(q7.z) & 0x7fffffffu), q7.w);
+        h.backface = (__float_as_uint(q7.z) >> 31) != 0u;
         laneDone = false;
         inTrav = true;
         pathActive = true;
@@ -1123,7 +1123,9 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     {
                         float4* const cold = PX_COLD(c);
                         cold[0] = make_float4(focusPoint.x, focusPoint.y, focusPoint.z, __uint_as_float(pixelIndex));
-                        cold[RT_WAVE] = make_float4(__uint_as_float((uint32_t)lrow * c.W + (uint32_t)x), __uint_as_float(segments), __uint_as_float((uint32_t)poolFrame), 0.0f);
+                        /* (the fourth word: the pixel's tile, for the tile cost written when the pixel is finished — no division there) */
+                        cold[RT_WAVE] = make_float4(__uint_as_float((uint32_t)lrow * c.W + (uint32_t)x), __uint_as_float(segments), __uint_as_float((uint32_t)poolFrame),
+                                                    __uint_as_float((uint32_t)(lrow >> 3) * (uint32_t)c.tilesX + (uint32_t)(x >> 3)));
                     }
                     PXU(PX_SAMPLE) = 0;
                     PXF(PX_TIX) = 0.0f; PXF(PX_TIY) = 0.0f; PXF(PX_TIZ) = 0.0f;
@@ -1264,16 +1266,17 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                         }
                     }
                     const int nextFrame = frameNow + 1;
-                    /* the item ends at a multiple of frameGroup past frame0, or with the launch (once per pixel and frame:
-                     * the integer division costs nothing next to the frame's segments, an LDS field would cost occupancy) */
+                    /* the item ends frameGroup frames past its first one (items start at multiples of frameGroup past frame0), or with the launch.
+                     * No integer division on this path: SOME lane of a wave finishes a pixel in three iterations out of four on the headline scene, so
+                     * whatever this block costs is paid by the whole wave nearly every iteration (rounds 1-5 had three divisions here: ~ 90 instructions) */
                     /* groups exist in the FLAT variant only (the host keeps frameGroup at 1 otherwise): the BVH variants are
                      * register-bound and paid 1.3 % for carrying the branch without ever gaining from it */
-                    if (!FLAT || nextFrame >= c.frame0 + c.nFrames || (uint32_t)(nextFrame - c.frame0) % (uint32_t)c.frameGroup == 0u) {
+                    if (!FLAT || nextFrame >= c.frame0 + c.nFrames || nextFrame - frameFirst >= c.frameGroup) {
                         laneDone = true;
                         if (c.tileCost) { /* longest serial chain (per frame) of this tile's pixels: the next launches' queue order */
-                            const uint32_t prow = pixLinear / c.W, pcol = pixLinear - prow * c.W;
-                            uint32_t* const slot = c.tileCost + (prow >> 3) * (uint32_t)c.tilesX + (pcol >> 3);
-                            const uint32_t chain = FLAT ? (segments - segStart) / (uint32_t)c.frameGroup : segments - segStart;
+                            uint32_t* const slot = c.tileCost + __float_as_uint(rec.w);
+                            /* (scheduling only: a group size that is not a power of two rounds the per-frame figure up to the next one below) */
+                            const uint32_t chain = FLAT ? (segments - segStart) >> c.frameGroupShift : segments - segStart;
                             if (chain > *slot) atomicMax(slot, chain); /* the plain read may be stale (lower): then the atomic decides */
                         }
                     } else { /* the next frame of this item's group: same pixel, fresh seed (RC:552) */
