@@ -144,8 +144,6 @@ struct KArgs {
     /* the BVH variants' workgroups (round 6): wavesPerGroup waves, LDS = [hot cache: hotUnits x 16 B][wave 0's region][wave 1's] ...;
      * units [0, hotUnits) of the pair space are the top-of-tree records the workgroup copies into LDS when it starts (rt_layout.h) */
     int32_t wavesPerGroup, hotUnits, waveLdsDwords;
-    int32_t poolCells;           /* the FLAT variant's chain pool: RT_POOL_CELLS, or 0 = single-wave workgroups without a pool;
-                                  * hotUnits then = the pool region's size in 16-byte units (the wave regions start behind it) */
     uint32_t travLimit;          /* traversal watchdog: iterations of one traverse() call no validated scene can reach (rt_kernels.h) */
     /* uniforms (RtParams) */
     int32_t maxBounce, spp, frame0, nFrames, seed, useSky, accumulate;
@@ -168,7 +166,6 @@ struct KArgs {
     int32_t launchItems;         /* queue positions of this launch: launchTiles, or launchTiles * frameGroups (tile, frame group) items */
     float4* pxCold;              /* per-wave pixel records of this launch: [grid][64 lanes][2] float4 (rt_kernels.h, PX_COLD) */
     int32_t frameGroup;          /* consecutive frames per item (>= 1) */
-    int32_t frameGroupShift;     /* floor(log2(frameGroup)): the tile cost's per-frame figure without a division */
     int32_t frameGroups;         /* ceil(nFrames / frameGroup) */
     float* staging;              /* nFrames > 1: [frame - frame0][stagingStride pixels] RGBA colours awaiting rt_accumulate_kernel */
     uint32_t stagingStride;
@@ -179,6 +176,10 @@ struct KArgs {
      * per-tile record of the longest pixel chain seen so far (segments in one frame) */
     const uint32_t* tileOrder;
     uint32_t* tileCost;
+    /* (round 6; at the end: the BVH variants' register allocation is sensitive to where their arguments lie) */
+    int32_t poolCells;           /* the FLAT variant's chain pool: RT_POOL_CELLS, or 0 = single-wave workgroups without a pool;
+                                  * hotUnits then = the pool region's size in 16-byte units (the wave regions start behind it) */
+    int32_t frameGroupShift;     /* floor(log2(frameGroup)): the tile cost's per-frame figure without a division */
 };
 
 #endif

@@ -1000,6 +1000,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
      * spatially close, but no lane idles while its tile mates finish their longer paths. */
     int poolX0 = 0, poolRow0 = 0, poolY0 = 0; /* pool tile: first column, first local row, first GLOBAL row */
     int poolPos = 0; /* next unassigned slot of the pool tile, 64 = exhausted */
+    int poolTile = 0; /* the pool tile's index among this context's tiles (the slot of its cost record) */
     int poolFrame = 0; /* the frame this pool tile is rendered for */
     /* A launch of nFrames > 1 frames hands out (tile, frame) items — queue position q = tile position q / nFrames, frame
      * q % nFrames — and a pixel's per-frame colours go to a staging slab that rt_accumulate_kernel adds up in frame order
@@ -1028,6 +1029,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
         const int ls_ = poolRow0 / (c).stripRows;                                                         \
         poolY0 = (ls_ * (c).partCount + (c).partIndex) * (c).stripRows + (poolRow0 - ls_ * (c).stripRows); \
         poolPos = 0;                                                                                      \
+        if (FLAT) poolTile = (tile);                                                                      \
     } while (0)
     {
         const RT_CAS KArgs& c = cold_args();
@@ -1123,9 +1125,10 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     {
                         float4* const cold = PX_COLD(c);
                         cold[0] = make_float4(focusPoint.x, focusPoint.y, focusPoint.z, __uint_as_float(pixelIndex));
-                        /* (the fourth word: the pixel's tile, for the tile cost written when the pixel is finished — no division there) */
+                        /* (the fourth word, FLAT variant: the pixel's tile, for the tile cost written when the pixel is finished — no division there.  The BVH
+                         * variants keep the division: a pixel ends once per thousands of their instructions, and one more live scalar costs them a spill) */
                         cold[RT_WAVE] = make_float4(__uint_as_float((uint32_t)lrow * c.W + (uint32_t)x), __uint_as_float(segments), __uint_as_float((uint32_t)poolFrame),
-                                                    __uint_as_float((uint32_t)(lrow >> 3) * (uint32_t)c.tilesX + (uint32_t)(x >> 3)));
+                                                    FLAT ? __uint_as_float((uint32_t)poolTile) : 0.0f);
                     }
                     PXU(PX_SAMPLE) = 0;
                     PXF(PX_TIX) = 0.0f; PXF(PX_TIY) = 0.0f; PXF(PX_TIZ) = 0.0f;
@@ -1144,92 +1147,6 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
             /* ... a wave of a pooled workgroup stays while a queue of the pool holds (or is being handed) a chain: whoever is alive takes it */
             if (RT_RFL(RT_POOL_LOAD(s_lds + 0)) == RT_RFL(RT_POOL_LOAD(s_lds + 3)) && RT_RFL(RT_POOL_LOAD(s_lds + 2)) == RT_RFL(RT_POOL_LOAD(s_lds + 1))) break; /* (head0, tail1, head1, tail0) */
         }
-        /* the second half of an iteration — the rest of one iteration of Trace's bounce loop for the lanes whose intersection is complete —
-         * as a callable: the pooled FLAT variant runs the chain exchange between the halves with every lane of the wave present */
-        auto shade_phase = [&]() __attribute__((always_inline)) {
-        if (inTrav && (FLAT || traverse<STATS, true, MANY, HOT>(a, rpos, rdir, stackBase, extBase, h, t, st, hotLds, hotUnits))) {
-            inTrav = false;
-            /* the rest of one iteration of Trace's bounce loop — RC:488-538 */
-            bool endPath = false;
-            if (h.obj < 0) {
-                phase_mark<STATS>(st, PH_SKY);
-                const RT_CAS KArgs& c = cold_args();
-                if (c.useSky) pathLight = pathLight + transmittance * environment_light(c, rdir);
-                endPath = true;
-            } else {
-                /* resolve the winner: position, normal, material */
-                phase_mark<STATS>(st, PH_SHADE_HIT);
-                rt_f3 hpos, normal;
-                resolve_hit(a, rpos, rdir, h, hpos, normal);
-                const DMaterial mat = a.materials[h.obj];
-
-                /* The glass (RC:499-518) and opaque (RC:519-533) branches both draw
-                 * diffuseDir = normalize(normal + RandomDirection) — the costliest piece
-                 * (3 log, 3 cos, 4 sqrt).  It is hoisted so that all hit lanes execute it
-                 * together; each lane still consumes its random numbers in its branch's
-                 * order: opaque = [isSpecular, direction x6], glass = [direction x6, choice]. */
-                const bool isGlass = mat.flag == RT_MATERIAL_GLASS;
-                float uSpec = 0.0f;
-                if (!isGlass) uSpec = rt_random_value(&rng); /* RC:521 */
-                const rt_f3 diffuseDir = rt_normalize(normal + rand_direction(&rng)); /* RC:509 / RC:525 */
-                /* Both branches end in normalize(lerp(A, B, t)) of a direction pair: opaque (diffuseDir, reflect, smoothness x
-                 * isSpecular), glass either (diffuseDir, reflect, specularProbability) or (-diffuseDir, refract, smoothness).  The
-                 * reference normalises both glass candidates and keeps one (RC:511-516); only the kept one is observable, so the
-                 * branches just pick (A, B, t) and ONE lerp + normalize follows for all hit lanes. */
-                const rt_f3 specularDir = rt_reflect(rdir, normal); /* == the glass branch's reflectDir, RC:419-422 */
-                rt_f3 lerpA = diffuseDir, lerpB = specularDir;
-                float lerpT;
-                if (isGlass) {
-                    phase_mark<STATS>(st, PH_GLASS);
-                    if (h.backface) { /* RC:502 */
-                        rt_f3 e = ((-h.dst) * rt_v3(mat.absorption[0], mat.absorption[1], mat.absorption[2])) * mat.absorptionStrength;
-                        transmittance = transmittance * rt_v3(rt_exp(e.x), rt_exp(e.y), rt_exp(e.z));
-                    }
-                    float iorCurrent = h.backface ? mat.ior : 1.0f;
-                    float iorNext = h.backface ? 1.0f : mat.ior;
-                    const rt_f3 refractDir = refract_dir(rdir, normal, iorCurrent, iorNext);
-                    const float reflectWeight = reflectance(rdir, normal, iorCurrent, iorNext);
-                    const bool followReflection = rt_random_value(&rng) <= reflectWeight; /* RC:515 */
-                    lerpT = mat.specularProbability;
-                    if (!followReflection) {
-                        lerpA = -diffuseDir;
-                        lerpB = refractDir;
-                        lerpT = mat.smoothness;
-                    }
-                } else {
-                    const bool isSpecular = mat.specularProbability >= uSpec;
-                    lerpT = mat.smoothness * (isSpecular ? 1.0f : 0.0f);
-                    rt_f3 emitted = rt_v3(mat.emissionCol[0], mat.emissionCol[1], mat.emissionCol[2]) * mat.emissionStrength;
-                    pathLight = pathLight + emitted * transmittance;
-                    transmittance = transmittance * material_colour(mat, hpos, normal, isSpecular);
-                }
-                rdir = rt_normalize(rt_lerp3(lerpA, lerpB, lerpT));
-                rpos = isGlass ? hpos + (0.001f * normal) * rt_sign(rt_dot(normal, rdir)) : hpos + (normal * 0.001f);
-                /* RC:535-538 Russian roulette */
-                float p = rt_max(transmittance.x, rt_max(transmittance.y, transmittance.z));
-                if (rt_random_value(&rng) >= p) {
-                    endPath = true;
-                } else {
-                    transmittance = transmittance * rt_rcp(p);
-                    if (MANY) {
-                        const uint32_t b = extBase[(1 + a.extWords) * RT_WAVE] + 1u;
-                        extBase[(1 + a.extWords) * RT_WAVE] = b;
-                        if ((int)b > a.maxBounce) endPath = true;
-                    } else {
-                        bounce++;
-                        if (bounce > a.maxBounce) endPath = true; /* RC:485: i <= MaxBounceCount */
-                    }
-                }
-            }
-            if (endPath) {
-                PXF(PX_TIX) = PXF(PX_TIX) + pathLight.x; /* RC:578: totalIncomingLight += Trace(...) */
-                PXF(PX_TIY) = PXF(PX_TIY) + pathLight.y;
-                PXF(PX_TIZ) = PXF(PX_TIZ) + pathLight.z;
-                pathActive = false;
-            }
-        
-        }
-        };
         if (!laneDone) {
         phase_mark<STATS>(st, PH_LOOP);
         if (!inTrav) {
@@ -1274,7 +1191,10 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     if (!FLAT || nextFrame >= c.frame0 + c.nFrames || nextFrame - frameFirst >= c.frameGroup) {
                         laneDone = true;
                         if (c.tileCost) { /* longest serial chain (per frame) of this tile's pixels: the next launches' queue order */
-                            uint32_t* const slot = c.tileCost + __float_as_uint(rec.w);
+                            uint32_t tileIdx;
+                            if (FLAT) tileIdx = __float_as_uint(rec.w);
+                            else { const uint32_t prow = pixLinear / c.W, pcol = pixLinear - prow * c.W; tileIdx = (prow >> 3) * (uint32_t)c.tilesX + (pcol >> 3); }
+                            uint32_t* const slot = c.tileCost + tileIdx;
                             /* (scheduling only: a group size that is not a power of two rounds the per-frame figure up to the next one below) */
                             const uint32_t chain = FLAT ? (segments - segStart) >> c.frameGroupShift : segments - segStart;
                             if (chain > *slot) atomicMax(slot, chain); /* the plain read may be stale (lower): then the atomic decides */
@@ -1282,7 +1202,7 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                     } else { /* the next frame of this item's group: same pixel, fresh seed (RC:552) */
                         rng = __float_as_uint(cold[0].w) + (uint32_t)nextFrame * 719393u + (uint32_t)c.seed;
                         sample = 0;
-                        PXU(PX_SAMPLE) = (uint32_t)(nextFrame - frameFirst) << 16;
+                        PXU(PX_SAMPLE) = (sampleWord & 0xffff0000u) + 0x10000u; /* (frame offset + 1) << 16: this branch exists for grouped items only */
                         PXF(PX_TIX) = 0.0f; PXF(PX_TIY) = 0.0f; PXF(PX_TIZ) = 0.0f;
                     }
                 }
@@ -1333,11 +1253,15 @@ __device__ __forceinline__ void trace_body(const KArgs& a)
                 if (FLAT) traverse_flat<STATS>(a, rpos, rdir, h, st);
             }
         }
-        if constexpr (!POOL) shade_phase();
+        if constexpr (!POOL) {
+#include "rt_shade_phase.inl"
+        }
         } /* !laneDone */
         if constexpr (POOL) {
             pool_exchange<STATS>(a, s_lds, lane, pxu, PX_COLD(cold_args()), laneDone, pathActive, inTrav, rpos, rdir, transmittance, pathLight, rng, bounce, h, segments, st);
-            if (!laneDone) shade_phase();
+            if (!laneDone) {
+#include "rt_shade_phase.inl"
+            }
         }
     }
 

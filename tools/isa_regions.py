@@ -11,7 +11,7 @@ ANCHORS = [  # (region name, text that starts it in rt_kernels.h); a region runs
     ("trav C: leaf", "---- C: one leaf"), ("trav: bottom vote", "        RT_TRAV_VOTE();\n    } while"), ("traverse_flat", "void traverse_flat("),
     ("resolve_hit", "void resolve_hit("), ("cold_args/wave_sum", "const RT_CAS KArgs& cold_args()"), ("prologue", ") rt_trace_kernel(const KArgs a)"),
     ("refill", "---- hand pixels to idle lanes"), ("frame end / accumulate", "phase_mark<STATS>(st, PH_LOOP)"), ("raygen", "next camera ray of this pixel"),
-    ("begin call", "phase_mark<STATS>(st, PH_SPHERES)"), ("sky", "the rest of one iteration of Trace's bounce loop"),
+    ("begin call", "phase_mark<STATS>(st, PH_SPHERES)"), ("pool exchange", "void pool_exchange("), ("pool call / loop tail", "if constexpr (POOL) {\n            pool_exchange"), ("sky", "/* the rest of one iteration of Trace's bounce loop — RC:488-538 */"),
     ("shade: common", "resolve the winner"), ("shade: glass", "phase_mark<STATS>(st, PH_GLASS)"),
     ("shade: opaque", "bool isSpecular = mat.specularProbability >= uSpec"), ("roulette/end path", "RC:535-538 Russian roulette"),
     ("epilogue", "exact work counters"), ("(other kernels)", "---- test hooks (rt_debug_*)")]
