@@ -89,6 +89,7 @@ struct RtContext {
     int stackEntries = 1; /* deepest BVH of the scene = most entries a lane can push */
     int wavesPerGroup = 1; /* the BVH variants' workgroups: waves that share one LDS top-of-tree cache (plan_groups) */
     uint32_t hotUnits = 0; /* units [0, hotUnits) of the pair space are that cache's records */
+    uint32_t poolSpinLimit = 1u << 16; /* the chain pool's watchdog (rt_kernels.h, pool_exchange); RT_POOL_FAULT=1 (test hook): 64 polls + the fault bit */
     int poolMinItems = 4; /* RT_POOL_MIN_ITEMS: (tile, frame) items per resident wave a launch needs to run as pooled workgroups (choose_variant) */
     int poolWaves = 1, poolCells = 0; /* the FLAT variant's workgroups: waves that share one LDS chain pool (rt_kernels.h, pool_exchange); poolCells = RT_POOL_CELLS or 0 = no pool */
     uint32_t travLimit = 1u << 20; /* traversal watchdog (rt_kernels.h, traverse): 64 x the steps one ray can take in this scene */
@@ -361,6 +362,7 @@ int rt_create(int device_id, RtContext** out)
     memset(&ctx->params, 0, sizeof(ctx->params));
     if (const char* g = getenv("RT_GRID")) ctx->gridOverride = atoi(g); /* tuning hook */
     if (const char* g = getenv("RT_POOL_MIN_ITEMS")) ctx->poolMinItems = atoi(g);
+    if (const char* g = getenv("RT_POOL_FAULT")) { if (atoi(g)) ctx->poolSpinLimit = 64u | 0x80000000u; }
     if (getenv("RT_VERBOSE")) ctx->verbose = true;
     if (const char* f = getenv("RT_FUSE_FRAMES")) ctx->fuseFrames = atoi(f) != 0;
     if (const char* l = getenv("RT_LPT")) ctx->lptEnabled = atoi(l) != 0;
@@ -1560,6 +1562,7 @@ static void fill_args(RtContext* ctx, int frame0, int nFrames, KArgs& a)
     a.hotUnits = 0;
     a.waveLdsDwords = 0;
     a.poolCells = 0;
+    a.poolSpinLimit = 1u << 16;
 }
 
 } /* extern "C" */
@@ -1700,6 +1703,7 @@ static int choose_variant(RtContext* ctx, KArgs& a, LaunchPlan& plan, bool* many
     a.wavesPerGroup = wpb;
     a.hotUnits = (int32_t)hotUnits;
     a.poolCells = pooled ? ctx->poolCells : 0;
+    a.poolSpinLimit = ctx->poolSpinLimit;
     a.waveLdsDwords = (int32_t)(waveBytes / sizeof(uint32_t));
     a.stackEntries = ctx->stackEntries;
     const bool many = ctx->nChunks > 0 && !ctx->flatScene;
@@ -2339,8 +2343,9 @@ int rt_get_counters(RtContext* ctx, RtCounters* out)
     out->modelVisits = sum[5];
     out->pixelFrames = ctx->pixelFrames;
     out->gpuMs = ctx->gpuMs;
-    /* slot 7 = the traversal watchdog (rt_kernels.h, traverse): a wave ended its lanes' walks because no validated scene needs that many steps */
-    if (h[7]) return fail(ctx, RT_ERR_HIP, "the traversal watchdog fired %llu times: a walk did not end (scene validation has a hole, or device memory is corrupt); the images since the last rt_reset_counters are not valid", h[7]);
+    /* slot 7 = the watchdogs (rt_kernels.h): traverse — a wave ended its lanes' walks because no validated scene needs that many steps; pool_exchange — a wave
+     * gave up waiting for a cell of the FLAT variant's chain pool */
+    if (h[7]) return fail(ctx, RT_ERR_HIP, "a kernel watchdog fired %llu times: a traversal did not end (scene validation has a hole, or device memory is corrupt) or, in a scene without trees, a cell of the chain pool was never handed over; the images since the last rt_reset_counters are not valid", h[7]);
     return RT_OK;
 }
 

@@ -180,6 +180,7 @@ struct KArgs {
     int32_t poolCells;           /* the FLAT variant's chain pool: RT_POOL_CELLS, or 0 = single-wave workgroups without a pool;
                                   * hotUnits then = the pool region's size in 16-byte units (the wave regions start behind it) */
     int32_t frameGroupShift;     /* floor(log2(frameGroup)): the tile cost's per-frame figure without a division */
+    uint32_t poolSpinLimit;      /* polls of a cell's sequence word before the chain pool's watchdog gives up (65,536); top bit: the RT_POOL_FAULT test hook */
 };
 
 #endif

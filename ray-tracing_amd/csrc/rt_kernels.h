@@ -812,14 +812,11 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
  *   withdraw: wait until seq[cell] == p + 1 (the writer is done), read the payload, seq[cell] = p + C (release: free for the next lap)
  * Every wait is for a wave that is in the middle of straight-line code of the same kind on an EARLIER position, so waits cannot form a
  * cycle; a wave never exits while it holds a chain or a queue is non-empty (trace_body), so every deposited chain is withdrawn by a
- * live wave.  A wait that exceeds RT_POOL_SPIN_LIMIT polls raises the watchdog counter (slot 7: rt_get_counters / rt_read_* then FAIL)
+ * live wave.  A wait that exceeds KArgs::poolSpinLimit (65,536) polls raises the watchdog counter (slot 7: rt_get_counters / rt_read_* then FAIL)
  * and goes on — a broken pool must cost a wrong image that says so, never a hung device.
  * ------------------------------------------------------------------------- */
 #ifndef RT_POOL_ATTEMPTS
 #define RT_POOL_ATTEMPTS 3 /* compare-and-swap attempts per exchange (config 2: 1 = -8.8 %, 2 = -10.0 %, 3 = -10.2 % frame time against no pool) */
-#endif
-#ifndef RT_POOL_SPIN_LIMIT
-#define RT_POOL_SPIN_LIMIT (1u << 16)
 #endif
 #define RT_POOL_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define RT_POOL_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -889,25 +886,34 @@ __device__ __forceinline__ void pool_exchange(const KArgs& a, uint32_t* const po
     uint32_t* const spW = seq + qt * C + cellW;
     /* both cells' sequence words in one go (every lane reads both; lanes without the role compare against what they read): the deposit's must say
      * "free for posD" (the reader of the previous lap is done), the withdrawal's "written for posW".  Almost always true at once. */
+    bool gaveUp = false;
     {
         uint32_t sD = RT_POOL_LOAD(spD), sW = RT_POOL_LOAD(spW);
-        if (__ballot((deposits && sD != posD) || (withdraws && sW != posW + 1u))) { /* rare: a writer / reader of the cell is in the middle of its copy */
+        /* (a.poolSpinLimit's top bit = the test hook RT_POOL_FAULT: withdrawers poll to the limit as if their cell were not written) */
+        const bool fault = (int)a.poolSpinLimit < 0;
+        if (__ballot((deposits && sD != posD) || (withdraws && sW != posW + 1u)) || fault) { /* rare: a writer / reader of the cell is in the middle of its copy */
             uint32_t spins = 0u;
             bool waiting = true;
             while (waiting) {
                 __builtin_amdgcn_s_sleep(1);
                 sD = RT_POOL_LOAD(spD);
                 sW = RT_POOL_LOAD(spW);
-                waiting = (deposits && sD != posD) || (withdraws && sW != posW + 1u);
-                if (++spins > RT_POOL_SPIN_LIMIT) { /* a broken pool costs a wrong image that says so (watchdog counter), never a hung device */
+                const bool notYet = (deposits && sD != posD) || (withdraws && sW != posW + 1u);
+                waiting = notYet || (fault && withdraws);
+                if (++spins > (a.poolSpinLimit & 0x7fffffffu)) {
+                    /* A broken pool costs a wrong image that says so (watchdog counter), never a hung device — and never a wild store: a lane whose cell
+                     * did not come DROPS its chain (nothing is written over a cell another wave may still read, nothing is read from a cell nobody
+                     * wrote) and goes on as an empty lane; whoever waits for that position gives up the same way. */
                     if (waiting) atomicAdd(a.counters + 7, 1ull);
+                    gaveUp = notYet;
                     waiting = false;
                 }
             }
         }
     }
     asm volatile("" ::: "memory"); /* the payload accesses below stay below the sequence reads (LDS executes a wave's instructions in order) */
-    if (deposits) {
+    if (deposits && gaveUp) { laneDone = true; inTrav = false; pathActive = false; }
+    if (deposits && !gaveUp) {
         float4* const q = payload + qo * (RT_POOL_QUADS * C) + cellD; /* quad j of the cell: q[j * C] */
         const float4 rec1 = cold[RT_WAVE];
         q[0 * C] = make_float4(rpos.x, rpos.y, rpos.z, __uint_as_float(rng));
@@ -928,7 +934,7 @@ __device__ __forceinline__ void pool_exchange(const KArgs& a, uint32_t* const po
         pathActive = false;
         if (STATS) st.hotSteps++;
     }
-    if (withdraws) {
+    if (withdraws && !gaveUp) {
         const float4* const q = payload + qt * (RT_POOL_QUADS * C) + cellW;
         const float4 q0 = q[0 * C], q1 = q[1 * C], q2 = q[2 * C], q3 = q[3 * C], q4 = q[4 * C], q5 = q[5 * C], q6 = q[6 * C], q7 = q[7 * C];
         asm volatile("" ::: "memory");

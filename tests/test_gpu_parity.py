@@ -961,6 +961,37 @@ def test_chain_pool_renders_the_same_bits(pkg, api, orc, env, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_chain_pool_watchdog_gives_up_instead_of_hanging_the_device(pkg, api, orc, monkeypatch):
+    """Round 6: the waves of a pooled workgroup wait for each other's cells (rt_kernels.h, pool_exchange) — never for long, and never in a cycle; but a wait
+    that cannot end must cost a failed render, not a hung device.  RT_POOL_FAULT=1 makes every withdrawing lane behave as if its cell were never written
+    (and lowers the limit from 65,536 polls to 64): the render calls return, rt_get_counters FAILS and says why — and the same process renders the same
+    scene correctly afterwards."""
+    monkeypatch.setenv("RT_POOL_MIN_ITEMS", "0")
+    monkeypatch.setenv("RT_POOL_FAULT", "1")
+    tr = api.create_tracer(0)
+    mgr = pkg.scenes.get(2).make_manager(tr, api, 96, 64)
+    mgr.OnEnable(renderSeed=2)
+    mgr.RenderFrames(3)
+    tr.synchronize()
+    with pytest.raises(pkg.abi.RtError) as e:
+        tr.counters()
+    assert "watchdog" in str(e.value)
+    tr.close()
+    monkeypatch.delenv("RT_POOL_FAULT")
+    tr = api.create_tracer(0)
+    mgr = pkg.scenes.get(2).make_manager(tr, api, 96, 64)
+    mgr.OnEnable(renderSeed=2)
+    mgr.RenderFrames(3)
+    good = tr.read_accumulated()
+    assert tr.counters()["segments"] > 0
+    tr.close()
+    ref = orc.create_tracer(4)
+    want, _ = render(pkg, orc, ref, 2, 96, 64, 3, seed=2)
+    ref.close()
+    assert np.array_equal(good.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
 def test_traversal_watchdog_ends_a_walk_instead_of_hanging_the_device(pkg, api, orc, monkeypatch):
     """Round 6: a traversal that does not end must not occupy the GPU for ever (missing 2: the reference walks its node indices
     with no check, RC:245-252).  The limit no validated scene can reach is 64 lanes x the steps one ray can take; forced down to 4 iterations
