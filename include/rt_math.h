@@ -32,6 +32,17 @@
 #define RT_HD inline
 #endif
 
+/* RT_WAVE_ALL(p) — device only: true when p holds in EVERY active lane of the wavefront.  The functions below keep their special cases
+ * (zeros, infinities, NaNs, subnormals, huge arguments) in per-lane branches; a per-lane branch costs the whole wave its exec-mask
+ * bookkeeping (four to six scalar instructions) even when no lane takes it, and the scalar unit is shared by all the waves of a compute
+ * unit.  With RT_WAVE_ALL(normal) in front, a wave whose active lanes are all ordinary runs the straight-line path behind ONE uniform
+ * branch; a wave with a special lane runs the unchanged per-lane code.  Same operations on the same values per lane either way. */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_MATH_NO_WAVE_PATHS)
+#define RT_WAVE_ALL(p) (__builtin_amdgcn_ballot_w64(!(p)) == 0ull)
+#else
+#define RT_WAVE_ALL(p) false
+#endif
+
 /* ---------------------------------------------------------------- bit casts */
 RT_HD uint32_t rt_f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 RT_HD float rt_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
@@ -46,7 +57,7 @@ RT_HD float rt_sqrt(float x) /* correctly rounded */
      * one exact-residual correction s + (x - s s) r/2 give the correctly rounded square root — checked over all 2^32 bit
      * patterns on gfx950 (tools/ubench/exact_math.hip: 0 mismatches in that range); zeros, negatives, tiny, huge, inf
      * and NaN arguments take the IEEE sequence. */
-    if ((rt_f2u(x) >> 23) - 32u <= 190u) {
+    if ((rt_f2u(x) >> 23) - 32u <= 190u) { /* (no wave-uniform copy here: it costs the BVH kernels a spill) */
         const float r = __builtin_amdgcn_rsqf(x);
         const float s = x * r;
         const float e = __builtin_fmaf(-s, s, x);
@@ -79,7 +90,13 @@ RT_HD float rt_rcp(float x)
      * checked over all 2^32 bit patterns against the compiler's 11-instruction IEEE sequence
      * (tools/ubench/exact_math.hip: 0 mismatches in that range); everything else — zeros, subnormals, the last two
      * binades, inf, NaN — takes the IEEE sequence. */
-    if (((rt_f2u(x) >> 23) & 0xffu) - 3u <= 248u) {
+    const bool ordinary = ((rt_f2u(x) >> 23) & 0xffu) - 3u <= 248u;
+    if (RT_WAVE_ALL(ordinary)) { /* wave-uniform branch */
+        const float y = __builtin_amdgcn_rcpf(x);
+        const float e = __builtin_fmaf(-x, y, 1.0f);
+        return __builtin_fmaf(y, e, y);
+    }
+    if (ordinary) {
         const float y = __builtin_amdgcn_rcpf(x);
         const float e = __builtin_fmaf(-x, y, 1.0f);
         return __builtin_fmaf(y, e, y);
@@ -138,6 +155,7 @@ RT_HD float rt_log(float x)
     const float Lg1 = 0.66666662693f, Lg2 = 0.40000972152f;
     const float Lg3 = 0.28498786688f, Lg4 = 0.24279078841f;
     uint32_t ix = rt_f2u(x);
+    /* (no wave-uniform path here: a second copy of the polynomial costs every trace kernel spilled registers — measured, profiles/r06_chain_pool.txt) */
     int k = 0;
     if (ix < 0x00800000u || (ix >> 31)) {
         if ((ix << 1) == 0) return -RT_INF;          /* log(+-0) = -inf  */
@@ -168,6 +186,31 @@ RT_HD float rt_log(float x)
 }
 
 /* ------------------------------------------------------------------- expf */
+/* the straight-line form of rt_exp below for |x| < 87.33655 (the result is normal: k in [-126, 126]) — the same operations with the magnitude
+ * classes as selects: k = 0 makes hi = x - 0 = x and lo = 0 exactly, y * 2^0 = y exactly, and |x| <= 2^-14 keeps its 1 + x.  Arguments that
+ * underflow to 0 (x <= -103.97..., -inf included: every pow(0, y)) are folded in with a stand-in.  Device only, behind RT_WAVE_ALL. */
+RT_HD float rt_exp_ordinary(float x)
+{
+    const float ln2hi = 6.9314575195e-1f, ln2lo = 1.4286067653e-6f, invln2 = 1.4426950216e+0f;
+    const float P1 = 1.6666625440e-1f, P2 = -2.7667332906e-3f;
+    uint32_t hx = rt_f2u(x);
+    const int sign = (int)(hx >> 31);
+    hx &= 0x7fffffffu;
+    const bool under = sign && hx >= 0x42cff1b5u;
+    if (under) { x = 0.0f; hx = 0u; }
+    const bool big = hx > 0x3f851592u, mid = hx > 0x3eb17218u, tiny = !(hx > 0x39000000u);
+    const int kb = (int)(invln2 * x + (sign ? -0.5f : 0.5f));
+    const int k = big ? kb : (mid ? 1 - sign - sign : 0);
+    const float fk = (float)k;
+    const float hi = x - fk * ln2hi;
+    const float lo = fk * ln2lo;
+    const float xr = hi - lo;
+    const float xx = xr * xr;
+    const float c = xr - xx * (P1 + xx * P2);
+    const float y = 1.0f + (rt_div_narrow(xr * c, 2.0f - c) - lo + hi);
+    const float r = y * rt_u2f((uint32_t)(k + 127) << 23);
+    return under ? 0.0f : (tiny ? 1.0f + x : r);
+}
 RT_HD float rt_exp(float x)
 {
     const float ln2hi = 6.9314575195e-1f;  /* 0x3f317200 */
@@ -177,6 +220,8 @@ RT_HD float rt_exp(float x)
     uint32_t hx = rt_f2u(x);
     int sign = (int)(hx >> 31);
     hx &= 0x7fffffffu;
+    /* wave-uniform branch: every lane's result is normal, or an underflow to 0 */
+    if (RT_WAVE_ALL(hx < 0x42aeac50u || (sign && hx >= 0x42cff1b5u && hx <= 0x7f800000u))) return rt_exp_ordinary(x);
     if (hx >= 0x42aeac50u) {               /* |x| >= 87.33655 or NaN */
         if (hx > 0x7f800000u) return x;    /* NaN */
         if (hx >= 0x42b17218u && !sign) return RT_INF;  /* overflow  */
@@ -250,6 +295,12 @@ RT_HD float rt_cos_kernel(float r)
 }
 RT_HD float rt_sin(float x)
 {
+    if (RT_WAVE_ALL(rt_abs(x) < 3.0e4f)) { /* wave-uniform branch */
+        float r;
+        int n = rt_reduce_pio2(x, &r);
+        float s = (n & 1) ? rt_cos_kernel(r) : rt_sin_kernel(r);
+        return (n & 2) ? -s : s;
+    }
     if (!(rt_abs(x) < 3.0e4f)) return (x != x || rt_abs(x) == RT_INF) ? rt_u2f(0x7fc00000u) : 0.0f;
     float r;
     int n = rt_reduce_pio2(x, &r);
@@ -258,6 +309,12 @@ RT_HD float rt_sin(float x)
 }
 RT_HD float rt_cos(float x)
 {
+    if (RT_WAVE_ALL(rt_abs(x) < 3.0e4f)) { /* wave-uniform branch */
+        float r;
+        int n = rt_reduce_pio2(x, &r);
+        float c = (n & 1) ? rt_sin_kernel(r) : rt_cos_kernel(r);
+        return ((n + 1) & 2) ? -c : c;
+    }
     if (!(rt_abs(x) < 3.0e4f)) return (x != x || rt_abs(x) == RT_INF) ? rt_u2f(0x7fc00000u) : 1.0f;
     float r;
     int n = rt_reduce_pio2(x, &r);
@@ -269,6 +326,16 @@ RT_HD float rt_cos(float x)
  * to calling rt_cos(x) and rt_sin(x) separately (same operations on the same r). */
 RT_HD void rt_sincos(float x, float* s_out, float* c_out)
 {
+    if (RT_WAVE_ALL(rt_abs(x) < 3.0e4f)) { /* wave-uniform branch */
+        float r;
+        int n = rt_reduce_pio2(x, &r);
+        float sk = rt_sin_kernel(r), ck = rt_cos_kernel(r);
+        float s = (n & 1) ? ck : sk;
+        float c = (n & 1) ? sk : ck;
+        *s_out = (n & 2) ? -s : s;
+        *c_out = ((n + 1) & 2) ? -c : c;
+        return;
+    }
     if (!(rt_abs(x) < 3.0e4f)) {
         *s_out = rt_sin(x);
         *c_out = rt_cos(x);
@@ -314,6 +381,14 @@ RT_HD rt_f3 rt_cross(rt_f3 a, rt_f3 b)
  * rsqrt(+-0) = +-inf, rsqrt(x<0) = NaN, rsqrt(inf) = 0, subnormals are pre-scaled by 2^48. */
 RT_HD float rt_rsqrt(float x)
 {
+    if (RT_WAVE_ALL(x >= 1.17549435e-38f && x < RT_INF)) { /* wave-uniform branch: positive, normal, finite in every lane — the steps below with scale = 1 */
+        float y = rt_u2f(0x5f375a86u - (rt_f2u(x) >> 1));
+        const float h = 0.5f * x;
+        y = y * (1.5f - h * y * y);
+        y = y * (1.5f - h * y * y);
+        y = y + y * (0.5f - h * y * y);
+        return y * 1.0f;
+    }
     if (!(x > 0.0f)) return (x == 0.0f) ? rt_u2f((rt_f2u(x) & 0x80000000u) | 0x7f800000u) : rt_u2f(0x7fc00000u);
     if (x == RT_INF) return 0.0f;
     float scale = 1.0f;

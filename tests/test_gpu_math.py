@@ -78,3 +78,50 @@ def test_fast_exact_sequences_equal_the_ieee_ones(api, orc, op):
     assert np.array_equal(np.isnan(got), nan)
     bad = got.view(np.uint32)[~nan] != want.view(np.uint32)[~nan]
     assert not bad.any(), (op, int(bad.sum()), x[~nan][bad][:5])
+
+
+@pytest.mark.parametrize("op", ["log", "exp", "sin", "cos", "sqrt", "rsqrt", "rcp", "pow"])
+def test_wave_uniform_paths_equal_the_per_lane_ones(api, orc, op):
+    """Round 6: on the device every function with special cases has a straight-line path behind RT_WAVE_ALL (include/rt_math.h) — taken when ALL active
+    lanes of a wavefront hold ordinary arguments — in front of the unchanged per-lane code.  The sweeps above mix special values into most wavefronts;
+    here every block of 64 consecutive arguments is of the fast class only — including the specials that class folds in with selects: log(+-0) = -inf,
+    log(1) = +0, exp of anything that underflows to 0 (-inf too), exp of |x| <= 2^-14 — so the straight-line paths are what runs; then the same arguments
+    with a NaN in every wavefront (the per-lane code runs) must give the same bits: both against the host."""
+    rng = np.random.default_rng(900 + OPS[op])
+    n = 64 * 6000
+    if op == "log":
+        x = np.exp(rng.uniform(-80, 80, n)).astype(np.float32)
+        x[rng.random(n) < 0.2] = 0.0
+        x[rng.random(n) < 0.05] = -0.0
+        x[rng.random(n) < 0.1] = 1.0
+    elif op == "exp":
+        x = rng.uniform(-87.3, 87.3, n).astype(np.float32)
+        x[rng.random(n) < 0.2] = rng.uniform(-1e-4, 1e-4)
+        sel = rng.random(n) < 0.15
+        x[sel] = rng.uniform(-1e4, -103.98, int(sel.sum())).astype(np.float32)
+        x[rng.random(n) < 0.1] = -np.inf
+        x[rng.random(n) < 0.05] = 0.0
+    elif op in ("sin", "cos"):
+        x = rng.uniform(-2.9e4, 2.9e4, n).astype(np.float32)
+        x[: n // 2] = rng.uniform(0, 6.2831855, n // 2).astype(np.float32)
+    elif op == "rcp":
+        x = (np.exp(rng.uniform(-85, 85, n)) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+    elif op in ("sqrt", "rsqrt"):
+        x = np.exp(rng.uniform(-60, 60, n)).astype(np.float32)
+    else:   # pow: the sky model's calls — pow(smoothstep in [0, 1], 0.35) and pow(max(0, dot), 1000 / sunFocus ...)
+        x = rng.uniform(0, 1, n).astype(np.float32)
+        x[rng.random(n) < 0.3] = 0.0
+        x[rng.random(n) < 0.2] = 1.0
+    y = rng.uniform(0.1, 900, n).astype(np.float32) if op == "pow" else None
+    tr = api.create_tracer(0)
+    for poison in (False, True):
+        xx = x.copy()
+        if poison:
+            xx[::64] = np.nan
+        got = tr.debug_math_eval(OPS[op], xx, y) if y is not None else tr.debug_math_eval(OPS[op], xx)
+        want = ev(orc, op, xx, y) if y is not None else ev(orc, op, xx)
+        nan = np.isnan(want)
+        assert np.array_equal(np.isnan(got), nan), (op, poison)
+        bad = got.view(np.uint32)[~nan] != want.view(np.uint32)[~nan]
+        assert not bad.any(), (op, poison, int(bad.sum()), xx[~nan][bad][:5])
+    tr.close()
